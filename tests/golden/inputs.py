@@ -1,0 +1,182 @@
+"""Deterministic synthetic inputs shared by make_golden.py (which feeds them to
+the reference) and the tests (which feed them to the oracle and the HIP path).
+numpy ``default_rng`` streams are stable across platforms, so only seeds travel.
+"""
+import numpy as np
+
+# ------------------------------------------------------------------ G1
+G1_OFFSET = 0.0
+G1_STEPS = 3
+G1_HYPER = dict(
+    sgd=dict(lr=0.02, momentum=0.9, weight_decay=1e-4),                     # schedule_1x_sgdnscl.py:21
+    sgd_nesterov=dict(lr=0.02, momentum=0.9, dampening=0.1, nesterov=True, weight_decay=1e-4),
+    adamw=dict(lr=1e-4, weight_decay=0.1),                                  # schedule_1x_sgdnscl.py:43 (commented AdamWNSCL)
+    adamw_amsgrad=dict(lr=1e-3, weight_decay=0.05, amsgrad=True),
+    adam=dict(lr=1e-3, weight_decay=1e-4),
+    sgdna=dict(lr=0.02, momentum=0.9, weight_decay=1e-4, thres=50.0),
+)
+
+_G1 = [
+    ("backbone.layer2.0.conv2.weight", (32, 32, 3, 3), True),
+    ("backbone.layer2.0.conv1.weight", (24, 96, 1, 1), True),
+    ("backbone.conv1.weight", (16, 3, 7, 7), True),
+    ("neck.fpn_convs.0.conv.weight", (16, 36, 3, 3), True),
+    ("neck.lateral_convs.0.conv.weight", (20, 160, 1, 1), True),
+    ("roi_head.fc.weight", (12, 40), True),
+    ("backbone.layer2.0.bn1.weight", (32,), False),
+    ("neck.fpn_convs.0.conv.bias", (16,), False),
+    ("rpn_head.rpn_conv.weight", (8, 8, 3, 3), False),
+]
+
+
+def g1_layers():
+    return [n for n, _, _ in _G1], [s for _, s, _ in _G1]
+
+
+def g1_projected():
+    return [n for n, _, p in _G1 if p]
+
+
+def g1_params():
+    out = []
+    for i, (_, shp, _) in enumerate(_G1):
+        rng = np.random.default_rng(100 + i)
+        out.append((rng.standard_normal(shp) * 0.02).astype(np.float32))
+    return out
+
+
+def g1_grads(step):
+    out = []
+    for i, (_, shp, _) in enumerate(_G1):
+        rng = np.random.default_rng(1000 + 37 * step + i)
+        out.append(rng.standard_normal(shp).astype(np.float32))
+    return out
+
+
+def covariance_like(D, seed, rows_mult=4):
+    """C = X^T X, X = [rows_mult*D, D] ~ N(0,1) * diag(logspace(0,-3,D))."""
+    rng = np.random.default_rng(seed)
+    X = rng.standard_normal((rows_mult * D, D)).astype(np.float32)
+    X *= np.logspace(0, -3, D).astype(np.float32)[None, :]
+    return (X.T @ X).astype(np.float32)
+
+
+def g1_covariances():
+    out = {}
+    for i, (n, shp, proj) in enumerate(_G1):
+        if proj:
+            D = int(np.prod(shp[1:]))
+            out[n] = covariance_like(D, 2000 + i)
+    return out
+
+
+# ------------------------------------------------------------------ G2
+G2_OFFSETS = [0.0, 0.3, -0.3, 2.0, 1.0, -1.0, -5.0]
+
+
+def g2_spectra():
+    out = []
+    rng = np.random.default_rng(4242)
+    for n in (16, 64, 100, 127, 128, 147, 256, 576, 1152, 2304):
+        out.append(np.logspace(2, -4, n).astype(np.float32))
+    for n in (96, 200, 600):  # plateau then cliff
+        k = n // 3
+        s = np.concatenate([np.full(k, 50.0), np.linspace(50, 1e-3, n - k)])
+        out.append(s.astype(np.float32))
+    for n in (120, 333, 1024):  # noisy exponential, sorted descending
+        s = np.exp(-np.arange(n) / (n / 12.0)) * (1 + 0.2 * rng.random(n))
+        out.append(np.sort(s)[::-1].astype(np.float32).copy())
+    for n in (80, 288):  # ties / zeros in the tail
+        s = np.logspace(1, -2, n)
+        s[n // 2:] = 0.0
+        s[5:9] = s[5]
+        out.append(s.astype(np.float32))
+    for D, seed in ((147, 7), (288, 8)):  # a real Gram spectrum
+        C = covariance_like(D, seed).astype(np.float64)
+        out.append(np.sort(np.linalg.eigvalsh(C))[::-1].astype(np.float32).copy())
+    return out
+
+
+# ------------------------------------------------------------------ G3
+def g3_cases():
+    return [
+        dict(kind="conv", cin=8, k=(1, 1), s=(1, 1), p=(0, 0), hw=(12, 10), batch=1),
+        dict(kind="conv", cin=6, k=(3, 3), s=(1, 1), p=(1, 1), hw=(9, 14), batch=2),
+        dict(kind="conv", cin=5, k=(3, 3), s=(2, 2), p=(1, 1), hw=(13, 11), batch=2),
+        dict(kind="conv", cin=3, k=(7, 7), s=(2, 2), p=(3, 3), hw=(20, 18), batch=1),
+        dict(kind="conv", cin=4, k=(3, 1), s=(1, 2), p=(0, 1), hw=(8, 9), batch=3),
+        dict(kind="linear", cin=24, batch=3),
+    ]
+
+
+def g3_inputs(ci, n_batches=2):
+    cfg = g3_cases()[ci]
+    out = []
+    for b in range(n_batches):
+        rng = np.random.default_rng(3000 + 10 * ci + b)
+        if cfg["kind"] == "conv":
+            shp = (cfg["batch"], cfg["cin"]) + cfg["hw"]
+        else:
+            shp = (cfg["batch"], cfg["cin"])
+        out.append(np.abs(rng.standard_normal(shp)).astype(np.float32))
+    return out
+
+
+# ------------------------------------------------------------------ G4
+G4_TASK_SPLIT = [0, 3, 5]
+G4_MAX_PROTO = 10
+G4_D = 7 * 7 * 256
+G4_SEED = 6
+# (rows, clusters) per class; classes 0-2 are the old task, 3-4 the new one
+G4_CLASSES = ((45, 4), (64, 6), (150, 16), (20, 4), (11, 4))
+
+
+def class_rois(n, d, seed, n_clusters=4, lo=0.25, hi=1.3):
+    """One class's RoI features: ``n_clusters`` ReLU'd Gaussian centres + per-row
+    noise of varying strength, ReLU'd (RoI features are post-ReLU, non-negative)."""
+    rng = np.random.default_rng(seed)
+    centres = np.maximum(rng.standard_normal((n_clusters, d)), 0).astype(np.float32)
+    which = rng.integers(0, n_clusters, size=n)
+    amp = rng.uniform(lo, hi, size=(n, 1)).astype(np.float32)
+    x = centres[which] + amp * rng.standard_normal((n, d)).astype(np.float32)
+    return np.maximum(x, 0).astype(np.float32)
+
+
+def g4_rois(seed=G4_SEED, classes=G4_CLASSES, d=G4_D):
+    feats, cls = [], []
+    for c, (n, k) in enumerate(classes):
+        feats.append(class_rois(n, d, seed * 100 + c, n_clusters=k))
+        cls.append(np.full(n, c, dtype=np.int64))
+    feats = np.concatenate(feats)
+    cls = np.concatenate(cls)
+    perm = np.random.default_rng(seed).permutation(len(cls))
+    return feats[perm], cls[perm]
+
+
+# ------------------------------------------------------------------ G5
+G5_TASK_SPLIT = [0, 3, 5, 7]
+G5_TASK_ID = 2
+G5_IN = 7 * 7 * 4
+G5_FC = 32
+
+
+def g5_weights():
+    rng = np.random.default_rng(77)
+
+    def lin(o, i, std):
+        return ((rng.standard_normal((o, i)) * std).astype(np.float32),
+                (rng.standard_normal(o) * 0.1).astype(np.float32))
+    w = dict(shared=[lin(G5_FC, G5_IN, 0.1), lin(G5_FC, G5_FC, 0.2)], cls=[], reg=[])
+    for i in range(1, len(G5_TASK_SPLIT)):
+        c = G5_TASK_SPLIT[i] - G5_TASK_SPLIT[i - 1]
+        w["cls"].append(lin(c, G5_FC, 0.3))
+        w["reg"].append(lin(4 * c, G5_FC, 0.05))
+    w["cls"].append(lin(1, G5_FC, 0.3))  # background
+    return w
+
+
+def g5_bank(k=14):
+    rng = np.random.default_rng(78)
+    bank = np.maximum(rng.standard_normal((k, G5_IN)), 0).astype(np.float32)
+    labels = rng.integers(0, G5_TASK_SPLIT[G5_TASK_ID - 1], size=k).astype(np.int64)
+    return bank, labels

@@ -1,0 +1,220 @@
+"""Generate the golden vectors under tests/golden/ by RUNNING THE REFERENCE.
+
+Run in the build container only (``python tests/golden/make_golden.py``):
+it executes the reference's own files from /root/reference through the
+stand-in loader in ``_ref_import.py`` and stores inputs' seeds + the
+reference's outputs as small ``.npz`` fixtures.  The tests regenerate the
+inputs from the same seeds with ``inputs.py`` (numpy Generator streams are
+stable) and never touch /root/reference.
+"""
+import os
+import sys
+import tempfile
+import warnings
+from collections import defaultdict
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+import _ref_import as R  # noqa: E402
+import inputs as I  # noqa: E402
+
+warnings.filterwarnings("ignore")
+torch.manual_seed(0)
+torch.set_num_threads(8)
+
+ref_sgd = R.load("mmdet/engine/optimizers/SGD_NSCL.py")
+ref_adamw = R.load("mmdet/engine/optimizers/AdamW_NSCL.py")
+ref_adam = R.load("mmdet/engine/optimizers/Adam_NSCL.py")
+ref_sgdna = R.load("mmdet/engine/optimizers/SGD_NSCL_NoAdaptive.py")
+ref_runner = R.load("mmdet/engine/runner/nsrunner_roi_replay.py")
+ref_head = R.load("mmdet/models/roi_heads/standard_roi_replay_head.py")
+ref_bbox = R.load("mmdet/models/roi_heads/bbox_heads/convfc_bbox_head_task.py")
+
+
+def save(name, **arrs):
+    path = os.path.join(HERE, name)
+    np.savez_compressed(path, **arrs)
+    print(f"{name}: {os.path.getsize(path) / 1024:.1f} KiB, {len(arrs)} arrays")
+
+
+# ---------------------------------------------------------------- G1 optimizers
+def run_optimizer(kind):
+    names, shapes = I.g1_layers()
+    params = [nn.Parameter(torch.from_numpy(a)) for a in I.g1_params()]
+    fea_in = {n: torch.from_numpy(c) for n, c in I.g1_covariances().items()}
+    hp = I.G1_HYPER[kind]
+    cls = dict(sgd=ref_sgd.SGDNSCL, sgd_nesterov=ref_sgd.SGDNSCL, adamw=ref_adamw.AdamWNSCL,
+               adamw_amsgrad=ref_adamw.AdamWNSCL, adam=ref_adam.AdamNSCL, sgdna=ref_sgdna.SGDNSCLNA)[kind]
+    opt = cls(params, svd=True, **hp)
+    opt.param_groups[0]["names"] = list(names)
+    opt.get_eigens(fea_in)
+    opt.get_transforms(offset=I.G1_OFFSET)
+    out = {}
+    for n in names:
+        if n in opt.transforms:
+            key = n.replace(".", "_")
+            out[f"sigma__{key}"] = opt.eigens[n]["eigen_value"].numpy()
+            if kind in ("sgd", "adam", "sgdna"):  # the others share sgd's projector rule
+                out[f"P__{key}"] = opt.transforms[n].numpy()
+            else:
+                out[f"Pnorm__{key}"] = opt.transforms[n].norm().numpy()
+    for step in range(I.G1_STEPS):
+        for p, g in zip(params, I.g1_grads(step)):
+            p.grad = torch.from_numpy(g)
+        opt.step()
+        for n, p in zip(names, params):
+            key = n.replace(".", "_")
+            out[f"p_step{step}__{key}"] = p.detach().numpy().copy()
+            out[f"g_step{step}__{key}"] = p.grad.numpy().copy()  # the reference mutates .grad
+    for n, p in zip(names, params):
+        key = n.replace(".", "_")
+        st = opt.state[p]
+        for sk in ("previous_grad", "exp_avg", "exp_avg_sq", "max_exp_avg_sq"):
+            if sk in st:
+                out[f"{sk}__{key}"] = st[sk].numpy().copy()
+    save(f"g1_{kind}.npz", **out)
+
+
+# ---------------------------------------------------------------- G2 thresholds
+def run_thresholds():
+    spectra = I.g2_spectra()
+    dummy = [nn.Parameter(torch.zeros(1))]
+    sgd = ref_sgd.SGDNSCL(dummy)
+    adamw = ref_adamw.AdamWNSCL(dummy)
+    out = {}
+    for si, s in enumerate(spectra):
+        t = torch.from_numpy(s)
+        for oi, off in enumerate(I.G2_OFFSETS):
+            m1 = sgd.adaptive_threshold(t, off).numpy()
+            m2 = adamw.adaptive_threshold(t, off).numpy()
+            m3 = ref_head.adaptive_threshold(t, off).numpy()
+            assert m1.any() and m2.any()
+            out[f"sgd_{si}_{oi}"] = np.int64(m1.argmax())
+            out[f"adam_{si}_{oi}"] = np.int64(m2.argmax())
+            out[f"head_{si}_{oi}"] = np.int64(m3.argmax())
+            assert m1[m1.argmax():].all() and not m1[:m1.argmax()].any()
+    save("g2_thresholds.npz", **out)
+
+
+# ---------------------------------------------------------------- G3 covariance
+def run_covariance():
+    Runner = ref_runner.BRNullSpaceRunner
+    out = {}
+    for ci, cfg in enumerate(I.g3_cases()):
+        if cfg["kind"] == "conv":
+            mod = nn.Conv2d(cfg["cin"], 4, cfg["k"], stride=cfg["s"], padding=cfg["p"], bias=False)
+        else:
+            mod = nn.Linear(cfg["cin"], 4, bias=False)
+        model = nn.Sequential()
+        model.add_module("layer", mod)
+        fake = object.__new__(Runner)
+        fake.model = model
+        fake.fea_in = defaultdict(dict)
+        h = mod.register_forward_hook(hook=fake.compute_cov)
+        with torch.no_grad():
+            for x in I.g3_inputs(ci):
+                model(torch.from_numpy(x))
+        h.remove()
+        (k, v), = fake.fea_in.items()
+        assert k == "layer.weight"
+        out[f"C_{ci}"] = v.numpy()
+    save("g3_covariance.npz", **out)
+
+
+# ---------------------------------------------------------------- G4 prototypes
+def run_prototypes():
+    feats, cls_t = I.g4_rois()
+    feats_t, cls_tt = torch.from_numpy(feats), torch.from_numpy(cls_t)
+    n = feats.shape[0]
+    rois = [feats_t, cls_tt, torch.ones(n), torch.zeros(n, 4), torch.zeros(n, 4), torch.zeros(n, 5)]
+    out = {}
+    with tempfile.TemporaryDirectory() as td:
+        prev = os.path.join(td, "x_15_5_1")
+        cur = os.path.join(td, "x_15_5_2")
+        os.makedirs(prev)
+        os.makedirs(cur)
+        torch.save(rois, os.path.join(prev, "rois_etc.pth"))
+        head = ref_head.StandardMultiPrototypeReplayHead(
+            previous_path=prev, task_id=2, task_split=I.G4_TASK_SPLIT, max_prototype=I.G4_MAX_PROTO)
+        masks = torch.load(os.path.join(cur, "mask.pth"))
+    out["bank"] = head.bbox_featss.numpy()
+    out["labels"] = head.tmp_label.numpy()
+    for c, ml in enumerate(masks):
+        out[f"nmask_{c}"] = np.int64(len(ml))
+        for j, m in enumerate(ml):
+            out[f"mask_{c}_{j}"] = m.numpy()
+        # the visiting order the reference used (same ops, same inputs, same build)
+        Fc = feats_t[cls_tt == c]
+        nrm = Fc.reshape(-1, 7 * 7 * 256) / Fc.reshape(-1, 7 * 7 * 256).norm(dim=-1, keepdim=True)
+        sim = nrm @ nrm.t()
+        cnt, idx = (sim >= 0.6).long().sum(dim=-1).sort(dim=-1, descending=True)
+        out[f"order_{c}"] = idx.numpy()
+        out[f"counts_{c}"] = (sim >= 0.6).long().sum(dim=-1).numpy()
+        sim64 = (Fc.double() / Fc.double().norm(dim=-1, keepdim=True))
+        sim64 = sim64 @ sim64.t()
+        out[f"margin_{c}"] = np.float64((sim64 - 0.6).abs().min().item())
+    save("g4_prototypes.npz", **out)
+    return head
+
+
+# ---------------------------------------------------------------- G5 replay loss
+class _TinyTaskHead(nn.Module):
+    """Carrier for the attributes ConvFCBBoxHeadTask.forward reads
+    (convfc_bbox_head_task.py:209-288); the forward itself is the reference's."""
+
+    def __init__(self, w):
+        super().__init__()
+        self.num_shared_convs, self.num_shared_fcs = 0, 2
+        self.with_avg_pool, self.with_cls, self.with_reg = False, True, True
+        self.reg_class_agnostic = False
+        self.task_split, self.task_id = I.G5_TASK_SPLIT, I.G5_TASK_ID
+        self.relu = nn.ReLU(inplace=True)
+        self.cls_convs, self.cls_fcs = nn.ModuleList(), nn.ModuleList()
+        self.reg_convs, self.reg_fcs = nn.ModuleList(), nn.ModuleList()
+
+        def lin(W, b):
+            m = nn.Linear(W.shape[1], W.shape[0])
+            m.weight.data = torch.from_numpy(W)
+            m.bias.data = torch.from_numpy(b)
+            return m
+        self.shared_fcs = nn.ModuleList([lin(*w["shared"][0]), lin(*w["shared"][1])])
+        self.fc_cls = nn.ModuleList([lin(*t) for t in w["cls"]])
+        self.fc_reg = nn.ModuleList([lin(*t) for t in w["reg"]])
+
+    forward = ref_bbox.ConvFCBBoxHeadTask.forward
+
+
+def run_replay_loss():
+    w = I.g5_weights()
+    bank, labels = I.g5_bank()
+    head = object.__new__(ref_head.StandardMultiPrototypeReplayHead)
+    nn.Module.__init__(head)
+    head.bbox_head = _TinyTaskHead(w)
+    head.task_split, head.task_id = I.G5_TASK_SPLIT, I.G5_TASK_ID
+    head.tmp_label = torch.from_numpy(labels)
+    type(head).with_shared_head = property(lambda self: False)
+    res = head.replay_loss(torch.from_numpy(bank), None, None)
+    loss = res["replay_loss"]["replay_loss_cls"]
+    loss.backward()
+    out = dict(loss=loss.detach().numpy(), cls_score=res["cls_score"].detach().numpy(),
+               bbox_pred=res["bbox_pred"].detach().numpy())
+    for i, m in enumerate(head.bbox_head.shared_fcs):
+        out[f"gW_shared{i}"] = m.weight.grad.numpy()
+        out[f"gb_shared{i}"] = m.bias.grad.numpy()
+    for i, m in enumerate(head.bbox_head.fc_cls):
+        out[f"gW_cls{i}"] = np.zeros_like(m.weight.detach().numpy()) if m.weight.grad is None else m.weight.grad.numpy()
+        out[f"has_grad_cls{i}"] = np.bool_(m.weight.grad is not None)
+    save("g5_replay_loss.npz", **out)
+
+
+if __name__ == "__main__":
+    for kind in ("sgd", "sgd_nesterov", "adamw", "adamw_amsgrad", "adam", "sgdna"):
+        run_optimizer(kind)
+    run_thresholds()
+    run_covariance()
+    run_prototypes()
+    run_replay_loss()
