@@ -1,0 +1,169 @@
+/*
+ * nsgp_repre.h -- C ABI of the MI355X-native NSGP-RePRE hot path (libnsgp_repre_hip.so)
+ *
+ * Drop-in boundary for the path SURVEY.md section 8 scopes.  The reference
+ * (yyl404/NSGP-RePRE) is pure Python on PyTorch; each entry point below replaces
+ * the torch call sequence at the cited reference file:line (paths relative to
+ * the reference repo root).  Plain pointers and sizes only: no torch types.
+ *
+ * Conventions
+ *   - every data pointer is a DEVICE pointer to contiguous fp32 unless noted;
+ *     the caller owns all buffers, the library borrows them for the call;
+ *   - work is enqueued on `stream` (a hipStream_t passed as void*; NULL = the
+ *     legacy default stream) and returns without synchronising;
+ *   - return value: NSGP_OK (0) or a negative NSGP_ERR_* code; no exceptions
+ *     cross the ABI; nsgp_last_error() gives a thread-local message;
+ *   - no allocation on the hot calls: step plans own their small device
+ *     tables (allocated in nsgp_plan_create), big workspaces are passed in.
+ */
+#ifndef NSGP_REPRE_H
+#define NSGP_REPRE_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define NSGP_OK 0
+#define NSGP_ERR_INVALID (-1)   /* bad argument (null pointer, negative size, misaligned) */
+#define NSGP_ERR_HIP (-2)       /* a HIP runtime call failed */
+#define NSGP_ERR_WORKSPACE (-3) /* workspace too small */
+#define NSGP_ERR_LIMIT (-4)     /* a fixed capacity was exceeded (e.g. > NSGP_MAX_HYPER combos) */
+
+#define NSGP_ABI_VERSION 1
+#define NSGP_MAX_HYPER 32 /* distinct hyper-parameter sets per plan step */
+
+int nsgp_abi_version(void);
+const char* nsgp_last_error(void);
+/* Number of HIP devices visible / name of the current one ("" without a GPU). */
+int nsgp_device_count(void);
+int nsgp_device_arch(char* buf, int buflen);
+
+/* ------------------------------------------------------------------------
+ * Projected optimizer step  (K1 + K2 of SURVEY section 2.2)
+ *
+ * Replaces the per-parameter Python loop of
+ *   SGDNSCL.step      mmdet/engine/optimizers/SGD_NSCL.py:59-96   (+ get_update :387-415)
+ *   AdamWNSCL.step    mmdet/engine/optimizers/AdamW_NSCL.py:66-103 (+ get_update :212-250)
+ *   AdamNSCL.step     mmdet/engine/optimizers/Adam_NSCL.py:66-102  (+ get_update :207-247)
+ *   SGDNSCLNA.step    mmdet/engine/optimizers/SGD_NSCL_NoAdaptive.py:59-111
+ * by two launches: one multi-tensor elementwise kernel over every listed
+ * tensor (momentum / Adam moments / weight decay, `p += update` for the
+ * un-projected ones) and one grouped fp32-MFMA GEMM `p += update.view(Cout,D) @ P`
+ * over every projected tensor (the `torch.mm(update.view(Cout,-1), P)` of
+ * SGD_NSCL.py:85-90).
+ * ------------------------------------------------------------------------ */
+
+typedef struct nsgp_plan nsgp_plan_t;
+
+enum { NSGP_OPT_SGD = 0, NSGP_OPT_ADAM = 1 };
+
+/* Static description of one parameter tensor (one (name, p) pair of the
+ * reference's param_groups[i]['names'/'params']). */
+typedef struct {
+    float* param;       /* p.data, numel fp32 */
+    float* state0;      /* SGD: state['previous_grad'];  Adam: state['exp_avg'] */
+    float* state1;      /* Adam: state['exp_avg_sq'];    SGD: NULL */
+    float* state2;      /* Adam amsgrad: state['max_exp_avg_sq'] or NULL */
+    const float* proj;  /* transforms[name]: [cols x cols] row-major, or NULL = not projected */
+    int64_t numel;
+    int32_t rows;       /* Cout  = update.size(0)            (projected tensors only) */
+    int32_t cols;       /* D     = numel / rows = Cin*kh*kw  (projected tensors only) */
+    int32_t hyper;      /* index into the per-step hyper array */
+    int32_t reserved;
+} nsgp_tensor_t;
+
+/* Per-step hyper-parameters of one param group (host values, fp64->fp32 as torch does). */
+typedef struct {
+    float lr;            /* SGD: group['lr'].  Adam: UNUSED for the moment update (see step_size) */
+    float momentum;      /* SGD */
+    float one_minus_dampening; /* SGD: (1 - group['dampening']) computed in double on the host */
+    float weight_decay;  /* SGD/Adam: L2 folded into grad.  AdamW: see decoupled_decay */
+    float beta1, beta2, one_minus_beta1, one_minus_beta2, eps; /* Adam */
+    float step_size;     /* Adam: lr*sqrt(1-beta2^t)/(1-beta1^t), computed in double on the host */
+    float decoupled_decay; /* AdamW: lr*weight_decay (AdamW_NSCL.py:87), else 0 */
+    int32_t nesterov;    /* SGD */
+    int32_t first_step;  /* SGD: state['step']==1 -> buf = grad (SGD_NSCL.py:403-406) */
+    int32_t amsgrad;     /* Adam */
+    int32_t write_grad;  /* 1 = mirror the reference's in-place mutation of p.grad */
+    int32_t reserved;
+} nsgp_hyper_t;
+
+/* Device bytes of update workspace a plan needs (Adam kinds: sum of projected numel*4; SGD: 0). */
+size_t nsgp_plan_workspace_bytes(const nsgp_tensor_t* tensors, int n_tensors, int optimizer);
+
+/* Build a plan: validates shapes, builds the cost-sorted, XCD-interleaved tile
+ * table of the grouped GEMM and the chunk table of the elementwise kernel, and
+ * uploads them.  `workspace` (device, >= nsgp_plan_workspace_bytes) is borrowed
+ * for the plan's lifetime.  Allocates a few hundred KB of device/pinned memory. */
+int nsgp_plan_create(nsgp_plan_t** plan, const nsgp_tensor_t* tensors, int n_tensors,
+                     int optimizer, void* workspace, size_t workspace_bytes);
+int nsgp_plan_destroy(nsgp_plan_t* plan);
+
+/* One optimizer step.  `grads[i]` = p.grad.data of tensor i (device pointers in a HOST
+ * array; may change from step to step).  `hyper` = n_hyper host structs.  Stream-ordered. */
+int nsgp_plan_step(nsgp_plan_t* plan, float* const* grads, const nsgp_hyper_t* hyper,
+                   int n_hyper, void* stream);
+
+/* Introspection for measurement: algorithmic FLOPs / bytes of one step of this plan
+ * (sum 2*Cout*D^2; sum 4*D^2 + 5*4*numel). */
+int nsgp_plan_stats(const nsgp_plan_t* plan, double* gemm_flops, double* algorithmic_bytes,
+                    int* n_tiles, int* n_projected);
+
+/* Stand-alone projection `out[rows x cols] (+)= scale * (a[rows x cols] @ proj[cols x cols])`
+ * (SGD_NSCL.py:85-90 in isolation; accumulate=0 overwrites `out`).  Used by tests to check
+ * the projected update itself at 1e-5 rel, which p += update cannot resolve in fp32. */
+int nsgp_project(const float* a, const float* proj, float* out, int rows, int cols, float scale,
+                 int accumulate, void* stream);
+
+/* ------------------------------------------------------------------------
+ * Covariance accumulation  (K3)
+ * Replaces BRNullSpaceRunner.compute_cov + update_cov,
+ *   mmdet/engine/runner/nsrunner_roi_replay.py:876-916, 923-934:
+ *   X = unfold(mean_batch(x), k, pad, stride) viewed [L x D];  C (+)= X^T X
+ * without materialising X (implicit im2col).  x: [B,Cin,H,W]; cov: [D x D], D=Cin*kh*kw.
+ * workspace: >= nsgp_cov_workspace_bytes (the zero-padded batch mean + the split-L partial tiles).
+ * accumulate=0 is the reference's first call (assign), 1 the later ones (add).
+ * ------------------------------------------------------------------------ */
+size_t nsgp_cov_workspace_bytes(int cin, int h, int w, int kh, int kw, int sh, int sw, int ph, int pw);
+int nsgp_cov_accumulate_conv2d(const float* x, int batch, int cin, int h, int w, int kh, int kw,
+                               int sh, int sw, int ph, int pw, float* cov, int accumulate,
+                               void* workspace, size_t workspace_bytes, void* stream);
+/* Linear branch (runner:901-902): X = mean(x, 0, keepdim) with x [B x F] -> C (+)= X^T X (rank 1). */
+int nsgp_cov_accumulate_linear(const float* x, int batch, int features, float* cov, int accumulate,
+                               void* stream);
+
+/* ------------------------------------------------------------------------
+ * Projector build  (K5)
+ * Replaces get_transforms, mmdet/engine/optimizers/SGD_NSCL.py:270-285:
+ *   basis = V[:, first_col:];  P = basis basis^T;  P /= ||P||_F if normalise.
+ * V: [D x D] row-major eigenvectors in columns (descending eigenvalue order), P: [D x D].
+ * scratch: >= nsgp_projector_scratch_bytes(D) of device memory (Frobenius-norm partial sums).
+ * ------------------------------------------------------------------------ */
+size_t nsgp_projector_scratch_bytes(int D);
+int nsgp_build_projector(const float* V, int D, int first_col, int normalise, float* P,
+                         void* scratch, size_t scratch_bytes, void* stream);
+
+/* ------------------------------------------------------------------------
+ * Prototype selection kernels  (K6, K7)
+ * Replace standard_roi_replay_head.py:417-423 (row-normalise -> F F^T -> >= thr ->
+ * row counts) and :413,443 (masked row means).
+ *   feats: [N x D] fp32.  norm_scratch: [N] floats (||row||_2, written by the call).
+ *   counts: [N] int64 (the reference's `.long().sum(-1)`).
+ *   bitmask: [N x words] uint64, words = (N+63)/64; bit j of row i = (sim[i][j] >= thr).
+ * ------------------------------------------------------------------------ */
+int repre_sim_counts(const float* feats, int n, int d, float thr, float* norm_scratch,
+                     int64_t* counts, uint64_t* bitmask, void* stream);
+/* out[d] = mean over rows i with bit i set in `rowmask` (words uint64); if rowmask==NULL all rows.
+ * n_selected is the popcount (caller-computed).  standard_roi_replay_head.py:413,443.
+ * workspace: >= repre_masked_mean_workspace_bytes(n, d) (per-row-segment partial sums). */
+size_t repre_masked_mean_workspace_bytes(int n, int d);
+int repre_masked_mean(const float* feats, int n, int d, const uint64_t* rowmask, int n_selected,
+                      float* out, void* workspace, size_t workspace_bytes, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* NSGP_REPRE_H */

@@ -1,0 +1,521 @@
+// Projected optimizer step: K1 (grouped fp32-MFMA projection GEMM) + K2 (multi-tensor
+// elementwise update).  Replaces the Python per-parameter loop of the reference's
+// SGDNSCL / AdamWNSCL / AdamNSCL / SGDNSCLNA `.step()`
+// (mmdet/engine/optimizers/SGD_NSCL.py:59-96,387-415; AdamW_NSCL.py:66-103,212-250;
+// Adam_NSCL.py:66-102,207-247).
+//
+// Launch 1  nsgp_update_kernel    HBM-bound. One pass over every listed tensor:
+//           weight decay, momentum / Adam moments, and `p += update` for tensors
+//           without a projector.  Projected tensors keep their update source for
+//           launch 2 (SGD: the momentum buffer or the mutated grad; Adam: workspace U).
+// Launch 2  nsgp_project_kernel   MFMA-bound. For every projected tensor
+//           p[Cout x D] += (scale * S[Cout x D]) @ P[D x D]  as 128x128 output tiles
+//           drawn from ONE cost-sorted tile table spanning all layers (longest K
+//           first = LPT list scheduling on the 256 CUs), interleaved so that tiles
+//           that share a P column panel land on the same XCD (blockIdx % 8).
+#include <algorithm>
+#include <cmath>
+#include <new>
+#include <vector>
+
+#include "common.hpp"
+#include "gemm_core.hpp"
+
+namespace nsgp {
+
+// ---- device-side tables ------------------------------------------------------
+struct TensorDev {
+    float* p;
+    float* s0;
+    float* s1;
+    float* s2;
+    float* u;  // Adam: slice of the update workspace (projected tensors only)
+    long numel;
+    int hyper;
+    int projected;
+};
+
+struct LayerDev {
+    float* p;
+    const float* s0;
+    const float* u;
+    const float* proj;
+    int tensor;
+    int rows, cols;
+    int hyper;
+};
+
+struct TileDev {
+    int layer, m0, n0, pad;
+};
+
+struct ChunkDev {
+    int tensor;
+    int pad;
+    long start;
+};
+
+constexpr int CHUNK = 16384;  // elements per workgroup of the elementwise kernel
+constexpr int NSLOT = 4;      // depth of the per-step upload ring
+
+struct DynBlock {  // uploaded every step: hyper sets + current grad pointers
+    nsgp_hyper_t hyper[NSGP_MAX_HYPER];
+    float* grads[1];  // n_tensors entries follow
+};
+
+// ---- launch 1: multi-tensor elementwise update -------------------------------
+// Rounding mirrors the ATen CPU kernels the reference runs: `x.add_(alpha, y)` is one
+// fused multiply-add per element, `mul_` then `add_` are two roundings.  The file is
+// built with -ffp-contract=off so nothing else is contracted.
+
+__device__ __forceinline__ void sgd_elem(float& p, float& g, float& b, const nsgp_hyper_t& h, bool projected) {
+    if (h.weight_decay != 0.0f) g = fmaf(h.weight_decay, p, g);  // grad.add_(wd, p)            :400
+    float d = g;
+    if (h.momentum != 0.0f) {
+        if (h.first_step) b = b + g;                                // exp_avg.add_(grad)          :406
+        else b = fmaf(h.one_minus_dampening, g, h.momentum * b);    // mul_(m).add_(1-damp, grad)  :404
+        if (h.nesterov) { g = fmaf(h.momentum, b, g); d = g; }      // grad.add_(m, exp_avg)       :409
+        else d = b;                                                 // grad = exp_avg              :411
+    }
+    if (!projected) p = p + (-(h.lr * d));                          // p.add_(-(lr*grad))          :413-414,95
+}
+
+__device__ __forceinline__ void adam_elem(float& p, float& g, float& m, float& v, float& vmax, float& u,
+                                          const nsgp_hyper_t& h, bool projected) {
+    if (h.weight_decay != 0.0f) g = fmaf(h.weight_decay, p, g);    // Adam_NSCL.py:229-230
+    m = fmaf(h.one_minus_beta1, g, h.beta1 * m);                    // exp_avg.mul_(b1).add_(1-b1, g)
+    v = fmaf(h.one_minus_beta2 * g, g, h.beta2 * v);                // exp_avg_sq.mul_(b2).addcmul_(1-b2, g, g)
+    float denom;
+    if (h.amsgrad) { vmax = fmaxf(vmax, v); denom = sqrtf(vmax) + h.eps; }
+    else denom = sqrtf(v) + h.eps;
+    float upd = ((-h.step_size) * m) / denom;                       // -step_size * exp_avg / denom
+    if (h.decoupled_decay != 0.0f) upd = upd - h.decoupled_decay * p;  // AdamW_NSCL.py:87
+    if (projected) u = upd; else p = p + upd;
+}
+
+template <int OPT>
+__global__ __launch_bounds__(256) void nsgp_update_kernel(const ChunkDev* __restrict__ chunks,
+                                                          const TensorDev* __restrict__ tensors,
+                                                          const DynBlock* __restrict__ dyn) {
+    const ChunkDev c = chunks[blockIdx.x];
+    const TensorDev T = tensors[c.tensor];
+    const nsgp_hyper_t h = dyn->hyper[T.hyper];
+    float* __restrict__ gp = dyn->grads[c.tensor];
+    const long end = (c.start + CHUNK < T.numel) ? c.start + CHUNK : T.numel;
+    const bool proj = T.projected != 0;
+    const bool vec = (((uintptr_t)T.p | (uintptr_t)gp | (uintptr_t)T.s0 | (uintptr_t)T.s1 | (uintptr_t)T.s2 |
+                       (uintptr_t)T.u) & 15u) == 0;
+    // the mutated gradient is the GEMM's A operand unless a non-Nesterov momentum buffer is
+    bool wg = h.write_grad != 0;
+    if (OPT == NSGP_OPT_SGD && proj && !(h.momentum != 0.0f && !h.nesterov)) wg = true;
+    long i = c.start + (long)threadIdx.x * 4;
+    if (vec) {
+        for (; i + 3 < end; i += 256 * 4) {
+            float4 p4 = *reinterpret_cast<const float4*>(T.p + i);
+            float4 g4 = *reinterpret_cast<const float4*>(gp + i);
+            float pv[4] = {p4.x, p4.y, p4.z, p4.w}, gv[4] = {g4.x, g4.y, g4.z, g4.w};
+            if (OPT == NSGP_OPT_SGD) {
+                float bv[4] = {0, 0, 0, 0};
+                if (h.momentum != 0.0f) {
+                    float4 b4 = *reinterpret_cast<const float4*>(T.s0 + i);
+                    bv[0] = b4.x; bv[1] = b4.y; bv[2] = b4.z; bv[3] = b4.w;
+                }
+#pragma unroll
+                for (int e = 0; e < 4; ++e) sgd_elem(pv[e], gv[e], bv[e], h, proj);
+                if (h.momentum != 0.0f) *reinterpret_cast<float4*>(T.s0 + i) = make_float4(bv[0], bv[1], bv[2], bv[3]);
+                if (wg && (h.weight_decay != 0.0f || (h.momentum != 0.0f && h.nesterov)))
+                    *reinterpret_cast<float4*>(gp + i) = make_float4(gv[0], gv[1], gv[2], gv[3]);
+                if (!proj) *reinterpret_cast<float4*>(T.p + i) = make_float4(pv[0], pv[1], pv[2], pv[3]);
+            } else {
+                float4 m4 = *reinterpret_cast<const float4*>(T.s0 + i);
+                float4 v4 = *reinterpret_cast<const float4*>(T.s1 + i);
+                float mv[4] = {m4.x, m4.y, m4.z, m4.w}, vv[4] = {v4.x, v4.y, v4.z, v4.w};
+                float xv[4] = {0, 0, 0, 0}, uv[4];
+                if (h.amsgrad) {
+                    float4 x4 = *reinterpret_cast<const float4*>(T.s2 + i);
+                    xv[0] = x4.x; xv[1] = x4.y; xv[2] = x4.z; xv[3] = x4.w;
+                }
+#pragma unroll
+                for (int e = 0; e < 4; ++e) adam_elem(pv[e], gv[e], mv[e], vv[e], xv[e], uv[e], h, proj);
+                *reinterpret_cast<float4*>(T.s0 + i) = make_float4(mv[0], mv[1], mv[2], mv[3]);
+                *reinterpret_cast<float4*>(T.s1 + i) = make_float4(vv[0], vv[1], vv[2], vv[3]);
+                if (h.amsgrad) *reinterpret_cast<float4*>(T.s2 + i) = make_float4(xv[0], xv[1], xv[2], xv[3]);
+                if (wg && h.weight_decay != 0.0f) *reinterpret_cast<float4*>(gp + i) = make_float4(gv[0], gv[1], gv[2], gv[3]);
+                if (proj) *reinterpret_cast<float4*>(T.u + i) = make_float4(uv[0], uv[1], uv[2], uv[3]);
+                else *reinterpret_cast<float4*>(T.p + i) = make_float4(pv[0], pv[1], pv[2], pv[3]);
+            }
+        }
+        // scalar tail of a tensor whose numel is not a multiple of 4
+        const long tail0 = end - ((end - c.start) & 3);
+        i = tail0 + threadIdx.x;
+        if (i >= end) return;
+    } else {
+        i = c.start + threadIdx.x;
+    }
+    const long stride = vec ? end : 256;  // vec: at most 3 tail elements, one per thread
+    for (; i < end; i += stride) {
+        float pv = T.p[i], gv = gp[i];
+        if (OPT == NSGP_OPT_SGD) {
+            float bv = (h.momentum != 0.0f) ? T.s0[i] : 0.0f;
+            sgd_elem(pv, gv, bv, h, proj);
+            if (h.momentum != 0.0f) T.s0[i] = bv;
+            if (wg && (h.weight_decay != 0.0f || (h.momentum != 0.0f && h.nesterov))) gp[i] = gv;
+            if (!proj) T.p[i] = pv;
+        } else {
+            float mv = T.s0[i], vv = T.s1[i], xv = h.amsgrad ? T.s2[i] : 0.0f, uv;
+            adam_elem(pv, gv, mv, vv, xv, uv, h, proj);
+            T.s0[i] = mv; T.s1[i] = vv;
+            if (h.amsgrad) T.s2[i] = xv;
+            if (wg && h.weight_decay != 0.0f) gp[i] = gv;
+            if (proj) T.u[i] = uv; else T.p[i] = pv;
+        }
+    }
+}
+
+// ---- launch 2: grouped projection GEMM ---------------------------------------
+template <bool FAST, bool ACCUM>
+__device__ __forceinline__ void store_tile(float* __restrict__ C, long ldc, int M, int N, int m0, int n0,
+                                           const f32x16 (&acc)[2][2]) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni) {
+            const int col = n0 + wn * 64 + ni * 32 + (lane & 31);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = m0 + wm * 64 + mi * 32 + acc_row(r, lane);
+                if (FAST || (row < M && col < N)) {
+                    float* dst = C + (long)row * ldc + col;
+                    *dst = ACCUM ? (*dst + acc[mi][ni][r]) : acc[mi][ni][r];
+                }
+            }
+        }
+}
+
+template <int OPT, bool FAST>
+__global__ __launch_bounds__(256, 2) void nsgp_project_kernel(const TileDev* __restrict__ tiles,
+                                                              const LayerDev* __restrict__ layers,
+                                                              const DynBlock* __restrict__ dyn) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const TileDev t = tiles[blockIdx.x];
+    const LayerDev L = layers[t.layer];
+    const float* A;
+    float scale;
+    if (OPT == NSGP_OPT_SGD) {
+        const nsgp_hyper_t& h = dyn->hyper[L.hyper];
+        // update = -(lr * grad) where `grad` is the momentum buffer (non-Nesterov momentum)
+        // or the (mutated) gradient itself (SGD_NSCL.py:408-414)
+        A = (h.momentum != 0.0f && !h.nesterov) ? L.s0 : dyn->grads[L.tensor];
+        scale = -h.lr;
+    } else {
+        A = L.u;
+        scale = 1.0f;
+    }
+    f32x16 acc[2][2];
+    zero_acc(acc);
+    // the grad pointer is only known at step time: a misaligned one (e.g. a view into a flat
+    // bucket) takes the guarded scalar loader for the A operand only
+    if (!FAST || ((uintptr_t)A & 15u) == 0)
+        gemm_tile<FAST, FAST, false>(A, L.cols, L.proj, L.cols, L.rows, L.cols, L.cols, t.m0, t.n0, scale, smem, acc);
+    else
+        gemm_tile<false, true, false>(A, L.cols, L.proj, L.cols, L.rows, L.cols, L.cols, t.m0, t.n0, scale, smem, acc);
+    store_tile<FAST, true>(L.p, L.cols, L.rows, L.cols, t.m0, t.n0, acc);  // p.data.add_(update_)  :95
+}
+
+template <bool FAST>
+__global__ __launch_bounds__(256, 2) void nsgp_project_single_kernel(const float* __restrict__ A,
+                                                                     const float* __restrict__ P,
+                                                                     float* __restrict__ out, int rows, int cols,
+                                                                     float scale, int accumulate) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    f32x16 acc[2][2];
+    zero_acc(acc);
+    const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+    gemm_tile<FAST, FAST, false>(A, cols, P, cols, rows, cols, cols, m0, n0, scale, smem, acc);
+    if (accumulate) store_tile<FAST, true>(out, cols, rows, cols, m0, n0, acc);
+    else store_tile<FAST, false>(out, cols, rows, cols, m0, n0, acc);
+}
+
+// ---- host: plan ---------------------------------------------------------------
+template <typename K>
+static int enable_big_lds(K kernel) {
+    NSGP_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel),
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, SMEM_BYTES));
+    return NSGP_OK;
+}
+
+}  // namespace nsgp
+
+using namespace nsgp;
+
+struct nsgp_plan {
+    int optimizer = 0;
+    int n_tensors = 0;
+    int n_layers = 0;
+    int n_chunks = 0;
+    int n_tiles_fast = 0, n_tiles_generic = 0;
+    double gemm_flops = 0, bytes = 0;
+    TensorDev* d_tensors = nullptr;
+    LayerDev* d_layers = nullptr;
+    TileDev* d_tiles = nullptr;  // fast tiles first, generic after
+    ChunkDev* d_chunks = nullptr;
+    size_t dyn_bytes = 0;
+    char* h_dyn[NSLOT] = {nullptr, nullptr, nullptr, nullptr};  // pinned
+    char* d_dyn[NSLOT] = {nullptr, nullptr, nullptr, nullptr};
+    hipEvent_t ev[NSLOT] = {nullptr, nullptr, nullptr, nullptr};
+    bool ev_used[NSLOT] = {false, false, false, false};
+    int slot = 0;
+};
+
+static bool tensor_fast(const nsgp_tensor_t& t) {
+    return t.rows % BM == 0 && t.cols % BN == 0 && t.cols % BK == 0 && aligned16(t.proj);
+}
+
+extern "C" size_t nsgp_plan_workspace_bytes(const nsgp_tensor_t* tensors, int n, int optimizer) {
+    if (optimizer != NSGP_OPT_ADAM || !tensors) return 0;
+    size_t s = 0;
+    for (int i = 0; i < n; ++i)
+        if (tensors[i].proj) s += ((size_t)tensors[i].numel * 4 + 255) & ~(size_t)255;
+    return s;
+}
+
+extern "C" int nsgp_plan_create(nsgp_plan_t** out, const nsgp_tensor_t* tensors, int n, int optimizer,
+                                void* workspace, size_t workspace_bytes) {
+    if (!out || !tensors || n <= 0) return fail(NSGP_ERR_INVALID, "nsgp_plan_create: null/empty tensor list");
+    if (optimizer != NSGP_OPT_SGD && optimizer != NSGP_OPT_ADAM)
+        return fail(NSGP_ERR_INVALID, "nsgp_plan_create: unknown optimizer %d", optimizer);
+    const size_t need = nsgp_plan_workspace_bytes(tensors, n, optimizer);
+    if (need > workspace_bytes || (need && !workspace))
+        return fail(NSGP_ERR_WORKSPACE, "nsgp_plan_create: workspace %zu < %zu bytes", workspace_bytes, need);
+
+    std::vector<TensorDev> td(n);
+    std::vector<LayerDev> ld;
+    std::vector<ChunkDev> cd;
+    std::vector<char> layer_fast;
+    double flops = 0, bytes = 0;
+    size_t ws_off = 0;
+    for (int i = 0; i < n; ++i) {
+        const nsgp_tensor_t& t = tensors[i];
+        if (!t.param || t.numel <= 0) return fail(NSGP_ERR_INVALID, "tensor %d: null param or numel<=0", i);
+        if (t.hyper < 0 || t.hyper >= NSGP_MAX_HYPER) return fail(NSGP_ERR_LIMIT, "tensor %d: hyper index %d", i, t.hyper);
+        if (!t.state0) return fail(NSGP_ERR_INVALID, "tensor %d: state0 is null", i);
+        if (optimizer == NSGP_OPT_ADAM && !t.state1) return fail(NSGP_ERR_INVALID, "tensor %d: Adam needs state1", i);
+        TensorDev d{t.param, t.state0, t.state1, t.state2, nullptr, (long)t.numel, t.hyper, t.proj ? 1 : 0};
+        if (t.proj) {
+            if (t.rows <= 0 || t.cols <= 0 || (int64_t)t.rows * t.cols != t.numel)
+                return fail(NSGP_ERR_INVALID, "tensor %d: rows*cols (%d*%d) != numel %lld", i, t.rows, t.cols,
+                            (long long)t.numel);
+            if (optimizer == NSGP_OPT_ADAM) {
+                d.u = reinterpret_cast<float*>(static_cast<char*>(workspace) + ws_off);
+                ws_off += ((size_t)t.numel * 4 + 255) & ~(size_t)255;
+            }
+            ld.push_back(LayerDev{t.param, t.state0, d.u, t.proj, i, t.rows, t.cols, t.hyper});
+            layer_fast.push_back(tensor_fast(t) && aligned16(t.param) && aligned16(t.state0) ? 1 : 0);
+            flops += 2.0 * t.rows * (double)t.cols * t.cols;
+            bytes += 4.0 * (double)t.cols * t.cols;
+        }
+        bytes += 5.0 * 4.0 * (double)t.numel;
+        td[i] = d;
+        for (long s = 0; s < t.numel; s += CHUNK) cd.push_back(ChunkDev{i, 0, s});
+    }
+
+    // ---- tile table.  Layers are grouped by K (= cols, the per-tile cost) in descending order, so
+    // the hardware's in-order dispatch of blockIdx does longest-first list scheduling on the 256
+    // CUs.  Inside one K group the tiles go to 8 queues keyed on their P column panel and the
+    // queues are interleaved round-robin: tiles 8 apart (same blockIdx % 8 = same XCD under the
+    // observed round-robin placement; speed only, never correctness) walk the M blocks of one
+    // panel, so a panel is fetched from HBM once and re-read from that XCD's L2.
+    std::vector<int> order(ld.size());
+    for (size_t i = 0; i < order.size(); ++i) order[i] = (int)i;
+    std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return ld[a].cols > ld[b].cols; });
+    std::vector<TileDev> fast_tiles, gen_tiles;
+    for (int pass = 0; pass < 2; ++pass) {
+        std::vector<TileDev>& dst = pass == 0 ? fast_tiles : gen_tiles;
+        size_t g0 = 0;
+        while (g0 < order.size()) {
+            size_t g1 = g0;
+            while (g1 < order.size() && ld[order[g1]].cols == ld[order[g0]].cols) ++g1;
+            std::vector<TileDev> q[8];
+            int rot = 0;
+            for (size_t oi = g0; oi < g1; ++oi) {
+                const int li = order[oi];
+                if ((layer_fast[li] != 0) != (pass == 0)) continue;
+                const int mb = (ld[li].rows + BM - 1) / BM, nb = (ld[li].cols + BN - 1) / BN;
+                for (int j = 0; j < nb; ++j)
+                    for (int m = 0; m < mb; ++m) q[(j + rot) & 7].push_back(TileDev{li, m * BM, j * BN, 0});
+                rot += nb;
+            }
+            size_t pos[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+            size_t total = 0;
+            for (auto& v : q) total += v.size();
+            const size_t base = dst.size();
+            while (dst.size() - base < total) {
+                for (int x = 0; x < 8 && dst.size() - base < total; ++x) {
+                    int src = x;
+                    if (pos[src] >= q[src].size()) {  // queue ran dry: borrow from the fullest
+                        size_t best = 0;
+                        src = -1;
+                        for (int y = 0; y < 8; ++y)
+                            if (q[y].size() - pos[y] > best) { best = q[y].size() - pos[y]; src = y; }
+                        if (src < 0) break;
+                    }
+                    dst.push_back(q[src][pos[src]++]);
+                }
+            }
+            g0 = g1;
+        }
+    }
+
+    nsgp_plan* P = new (std::nothrow) nsgp_plan();
+    if (!P) return fail(NSGP_ERR_INVALID, "out of host memory");
+    P->optimizer = optimizer;
+    P->n_tensors = n;
+    P->n_layers = (int)ld.size();
+    P->n_chunks = (int)cd.size();
+    P->n_tiles_fast = (int)fast_tiles.size();
+    P->n_tiles_generic = (int)gen_tiles.size();
+    P->gemm_flops = flops;
+    P->bytes = bytes;
+    std::vector<TileDev> all_tiles(fast_tiles);
+    all_tiles.insert(all_tiles.end(), gen_tiles.begin(), gen_tiles.end());
+    P->dyn_bytes = (sizeof(nsgp_hyper_t) * NSGP_MAX_HYPER + sizeof(float*) * (size_t)n + 255) & ~(size_t)255;
+
+#define PLAN_HIP(call)                                                                               \
+    do {                                                                                             \
+        hipError_t e_ = (call);                                                                      \
+        if (e_ != hipSuccess) {                                                                      \
+            nsgp_plan_destroy(P);                                                                    \
+            return fail(NSGP_ERR_HIP, "%s failed: %s", #call, hipGetErrorString(e_));                \
+        }                                                                                            \
+    } while (0)
+    PLAN_HIP(hipMalloc(&P->d_tensors, sizeof(TensorDev) * td.size()));
+    PLAN_HIP(hipMemcpy(P->d_tensors, td.data(), sizeof(TensorDev) * td.size(), hipMemcpyHostToDevice));
+    PLAN_HIP(hipMalloc(&P->d_chunks, sizeof(ChunkDev) * cd.size()));
+    PLAN_HIP(hipMemcpy(P->d_chunks, cd.data(), sizeof(ChunkDev) * cd.size(), hipMemcpyHostToDevice));
+    if (!ld.empty()) {
+        PLAN_HIP(hipMalloc(&P->d_layers, sizeof(LayerDev) * ld.size()));
+        PLAN_HIP(hipMemcpy(P->d_layers, ld.data(), sizeof(LayerDev) * ld.size(), hipMemcpyHostToDevice));
+        PLAN_HIP(hipMalloc(&P->d_tiles, sizeof(TileDev) * all_tiles.size()));
+        PLAN_HIP(hipMemcpy(P->d_tiles, all_tiles.data(), sizeof(TileDev) * all_tiles.size(), hipMemcpyHostToDevice));
+    }
+    for (int s = 0; s < NSLOT; ++s) {
+        PLAN_HIP(hipHostMalloc(reinterpret_cast<void**>(&P->h_dyn[s]), P->dyn_bytes, hipHostMallocDefault));
+        PLAN_HIP(hipMalloc(reinterpret_cast<void**>(&P->d_dyn[s]), P->dyn_bytes));
+        PLAN_HIP(hipEventCreateWithFlags(&P->ev[s], hipEventDisableTiming));
+    }
+#undef PLAN_HIP
+    int rc;
+    if ((rc = enable_big_lds(nsgp_project_kernel<NSGP_OPT_SGD, true>)) || (rc = enable_big_lds(nsgp_project_kernel<NSGP_OPT_SGD, false>)) ||
+        (rc = enable_big_lds(nsgp_project_kernel<NSGP_OPT_ADAM, true>)) || (rc = enable_big_lds(nsgp_project_kernel<NSGP_OPT_ADAM, false>))) {
+        nsgp_plan_destroy(P);
+        return rc;
+    }
+    *out = P;
+    return NSGP_OK;
+}
+
+extern "C" int nsgp_plan_destroy(nsgp_plan_t* P) {
+    if (!P) return NSGP_OK;
+    for (int s = 0; s < NSLOT; ++s) {
+        if (P->ev[s]) { (void)hipEventSynchronize(P->ev[s]); (void)hipEventDestroy(P->ev[s]); }
+        if (P->h_dyn[s]) (void)hipHostFree(P->h_dyn[s]);
+        if (P->d_dyn[s]) (void)hipFree(P->d_dyn[s]);
+    }
+    if (P->d_tensors) (void)hipFree(P->d_tensors);
+    if (P->d_layers) (void)hipFree(P->d_layers);
+    if (P->d_tiles) (void)hipFree(P->d_tiles);
+    if (P->d_chunks) (void)hipFree(P->d_chunks);
+    delete P;
+    return NSGP_OK;
+}
+
+extern "C" int nsgp_plan_stats(const nsgp_plan_t* P, double* gemm_flops, double* bytes, int* n_tiles, int* n_proj) {
+    if (!P) return fail(NSGP_ERR_INVALID, "nsgp_plan_stats: null plan");
+    if (gemm_flops) *gemm_flops = P->gemm_flops;
+    if (bytes) *bytes = P->bytes;
+    if (n_tiles) *n_tiles = P->n_tiles_fast + P->n_tiles_generic;
+    if (n_proj) *n_proj = P->n_layers;
+    return NSGP_OK;
+}
+
+extern "C" int nsgp_plan_step(nsgp_plan_t* P, float* const* grads, const nsgp_hyper_t* hyper, int n_hyper,
+                              void* stream_) {
+    if (!P || !grads || !hyper) return fail(NSGP_ERR_INVALID, "nsgp_plan_step: null argument");
+    if (n_hyper <= 0 || n_hyper > NSGP_MAX_HYPER)
+        return fail(NSGP_ERR_LIMIT, "nsgp_plan_step: n_hyper %d outside 1..%d", n_hyper, NSGP_MAX_HYPER);
+    for (int i = 0; i < P->n_tensors; ++i)
+        if (!grads[i]) return fail(NSGP_ERR_INVALID, "nsgp_plan_step: grad %d is null (the reference raises too)", i);
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    const int s = P->slot;
+    P->slot = (s + 1) % NSLOT;
+    if (P->ev_used[s]) NSGP_HIP(hipEventSynchronize(P->ev[s]));  // slot reuse: its last upload was consumed
+    DynBlock* h = reinterpret_cast<DynBlock*>(P->h_dyn[s]);
+    std::memset(h->hyper, 0, sizeof(h->hyper));
+    std::memcpy(h->hyper, hyper, sizeof(nsgp_hyper_t) * n_hyper);
+    std::memcpy(h->grads, grads, sizeof(float*) * (size_t)P->n_tensors);
+    NSGP_HIP(hipMemcpyAsync(P->d_dyn[s], P->h_dyn[s], P->dyn_bytes, hipMemcpyHostToDevice, stream));
+    const DynBlock* d = reinterpret_cast<const DynBlock*>(P->d_dyn[s]);
+
+    if (P->optimizer == NSGP_OPT_SGD)
+        hipLaunchKernelGGL(nsgp_update_kernel<NSGP_OPT_SGD>, dim3(P->n_chunks), dim3(256), 0, stream, P->d_chunks, P->d_tensors, d);
+    else
+        hipLaunchKernelGGL(nsgp_update_kernel<NSGP_OPT_ADAM>, dim3(P->n_chunks), dim3(256), 0, stream, P->d_chunks, P->d_tensors, d);
+    NSGP_LAUNCH_CHECK();
+    if (P->n_tiles_fast > 0) {
+        if (P->optimizer == NSGP_OPT_SGD)
+            hipLaunchKernelGGL((nsgp_project_kernel<NSGP_OPT_SGD, true>), dim3(P->n_tiles_fast), dim3(THREADS), SMEM_BYTES, stream, P->d_tiles, P->d_layers, d);
+        else
+            hipLaunchKernelGGL((nsgp_project_kernel<NSGP_OPT_ADAM, true>), dim3(P->n_tiles_fast), dim3(THREADS), SMEM_BYTES, stream, P->d_tiles, P->d_layers, d);
+        NSGP_LAUNCH_CHECK();
+    }
+    if (P->n_tiles_generic > 0) {
+        const TileDev* gt = P->d_tiles + P->n_tiles_fast;
+        if (P->optimizer == NSGP_OPT_SGD)
+            hipLaunchKernelGGL((nsgp_project_kernel<NSGP_OPT_SGD, false>), dim3(P->n_tiles_generic), dim3(THREADS), SMEM_BYTES, stream, gt, P->d_layers, d);
+        else
+            hipLaunchKernelGGL((nsgp_project_kernel<NSGP_OPT_ADAM, false>), dim3(P->n_tiles_generic), dim3(THREADS), SMEM_BYTES, stream, gt, P->d_layers, d);
+        NSGP_LAUNCH_CHECK();
+    }
+    NSGP_HIP(hipEventRecord(P->ev[s], stream));
+    P->ev_used[s] = true;
+    return NSGP_OK;
+}
+
+extern "C" int nsgp_project(const float* a, const float* proj, float* out, int rows, int cols, float scale,
+                            int accumulate, void* stream_) {
+    if (!a || !proj || !out || rows <= 0 || cols <= 0) return fail(NSGP_ERR_INVALID, "nsgp_project: bad argument");
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    const bool fast = rows % BM == 0 && cols % BN == 0 && aligned16(a) && aligned16(proj) && aligned16(out);
+    dim3 grid((cols + BN - 1) / BN, (rows + BM - 1) / BM);
+    int rc;
+    if (fast) {
+        if ((rc = enable_big_lds(nsgp_project_single_kernel<true>))) return rc;
+        hipLaunchKernelGGL(nsgp_project_single_kernel<true>, grid, dim3(THREADS), SMEM_BYTES, stream, a, proj, out, rows, cols, scale, accumulate);
+    } else {
+        if ((rc = enable_big_lds(nsgp_project_single_kernel<false>))) return rc;
+        hipLaunchKernelGGL(nsgp_project_single_kernel<false>, grid, dim3(THREADS), SMEM_BYTES, stream, a, proj, out, rows, cols, scale, accumulate);
+    }
+    NSGP_LAUNCH_CHECK();
+    return NSGP_OK;
+}
+
+// ---- misc ABI -----------------------------------------------------------------
+extern "C" int nsgp_abi_version(void) { return NSGP_ABI_VERSION; }
+extern "C" const char* nsgp_last_error(void) { return err_buf(); }
+extern "C" int nsgp_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+extern "C" int nsgp_device_arch(char* buf, int buflen) {
+    if (!buf || buflen <= 0) return NSGP_ERR_INVALID;
+    buf[0] = 0;
+    int dev = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess)
+        return fail(NSGP_ERR_HIP, "no HIP device");
+    std::snprintf(buf, buflen, "%s", prop.gcnArchName);
+    return NSGP_OK;
+}

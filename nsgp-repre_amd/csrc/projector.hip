@@ -1,0 +1,141 @@
+// K5: null-space projector build.  Replaces get_transforms
+// (mmdet/engine/optimizers/SGD_NSCL.py:270-285):
+//     basis = V[:, ind];  P = basis @ basis.T;  P /= ||P||_F   (if normalise)
+// where `ind` is always a column suffix [first_col, D) of V (adaptive_threshold sets
+// mask[i_thres:] = True, SGD_NSCL.py:174-175; the NoAdaptive rule `s <= s_min*thres`
+// on a descending spectrum is a suffix too).
+//
+// P is symmetric: only the 128x128 tiles on or above the diagonal are computed on
+// the fp32 MFMA core (A = B = V[:, first_col:], "rows" image for both operands) and
+// each is stored twice.  Loads start at the 32-aligned column below first_col with
+// the leading columns zeroed in the LDS write, so the aligned float4 path is kept.
+#include <algorithm>
+
+#include "common.hpp"
+#include "gemm_core.hpp"
+
+namespace nsgp {
+
+constexpr int NORM_BLOCKS = 1024;
+
+template <bool FAST>
+__global__ __launch_bounds__(256, 2) void nsgp_projector_kernel(const float* __restrict__ V, float* __restrict__ P,
+                                                                int D, int first_col) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    // blockIdx.x enumerates the upper-triangular tiles row by row
+    const int nb = (D + BM - 1) / BM;
+    int ti = 0, rem = blockIdx.x;
+    while (rem >= nb - ti) { rem -= nb - ti; ++ti; }
+    const int m0 = ti * BM, n0 = (ti + rem) * BN;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int wm = wave >> 1, wn = wave & 1;
+    f32x16 acc[2][2];
+    zero_acc(acc);
+    float ra[4][4], rb[4][4];
+    const int kbeg = first_col & ~(BK - 1);
+    const int nk = (D - kbeg + BK - 1) / BK;
+
+    stage_rows<FAST>(V, D, D, D, m0, kbeg, ra);
+    stage_rows<FAST>(V, D, D, D, n0, kbeg, rb);
+    write_rows_klo(a_img(smem, 0), ra, kbeg, first_col);
+    write_rows_klo(b_img(smem, 0), rb, kbeg, first_col);
+    __syncthreads();
+    for (int t = 0; t < nk; ++t) {
+        const int cur = t & 1;
+        const int knext = kbeg + (t + 1) * BK;
+        if (t + 1 < nk) {
+            stage_rows<FAST>(V, D, D, D, m0, knext, ra);
+            stage_rows<FAST>(V, D, D, D, n0, knext, rb);
+        }
+        mfma_kstep<true>(a_img(smem, cur), b_img(smem, cur), acc, wm, wn);
+        if (t + 1 < nk) {
+            write_rows_klo(a_img(smem, cur ^ 1), ra, knext, first_col);
+            write_rows_klo(b_img(smem, cur ^ 1), rb, knext, first_col);
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni) {
+            const int col = n0 + wn * 64 + ni * 32 + (lane & 31);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = m0 + wm * 64 + mi * 32 + acc_row(r, lane);
+                if (row < D && col < D) {
+                    P[(long)row * D + col] = acc[mi][ni][r];
+                    if (m0 != n0) P[(long)col * D + row] = acc[mi][ni][r];
+                }
+            }
+        }
+}
+
+// Frobenius norm, deterministic two-stage sum in double.
+__global__ __launch_bounds__(256) void nsgp_sumsq_partial_kernel(const float* __restrict__ P, long n, double* __restrict__ partial) {
+    __shared__ double red[4];
+    double s = 0.0;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+        const double v = P[i];
+        s += v * v;
+    }
+    for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) partial[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
+}
+
+__global__ __launch_bounds__(256) void nsgp_norm_final_kernel(double* __restrict__ partial, int n_partial) {
+    __shared__ double red[4];
+    double s = 0.0;
+    for (int i = threadIdx.x; i < n_partial; i += 256) s += partial[i];
+    for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    // slot NORM_BLOCKS holds the fp32 norm (torch.norm returns fp32) for the divide pass
+    if (threadIdx.x == 0) reinterpret_cast<float*>(partial + NORM_BLOCKS)[0] = (float)sqrt(red[0] + red[1] + red[2] + red[3]);
+}
+
+__global__ __launch_bounds__(256) void nsgp_divide_kernel(float* __restrict__ P, long n, const double* __restrict__ partial) {
+    const float nrm = reinterpret_cast<const float*>(partial + NORM_BLOCKS)[0];
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) P[i] = P[i] / nrm;
+}
+
+}  // namespace nsgp
+
+using namespace nsgp;
+
+extern "C" size_t nsgp_projector_scratch_bytes(int D) {
+    const int nb = (D + BM - 1) / BM;
+    (void)nb;
+    return (NORM_BLOCKS + 2) * sizeof(double);
+}
+
+extern "C" int nsgp_build_projector(const float* V, int D, int first_col, int normalise, float* P, void* scratch,
+                                    size_t scratch_bytes, void* stream_) {
+    if (!V || !P || D <= 0 || first_col < 0 || first_col >= D) return fail(NSGP_ERR_INVALID, "nsgp_build_projector: bad argument (D=%d first_col=%d)", D, first_col);
+    if (!scratch || scratch_bytes < nsgp_projector_scratch_bytes(D)) return fail(NSGP_ERR_WORKSPACE, "nsgp_build_projector: scratch too small");
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    const int nb = (D + BM - 1) / BM;
+    const int tiles = nb * (nb + 1) / 2;
+    double* partial = static_cast<double*>(scratch);
+    const bool fast = (D % BM == 0) && aligned16(V);
+    if (fast) {
+        NSGP_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(nsgp_projector_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, SMEM_BYTES));
+        hipLaunchKernelGGL(nsgp_projector_kernel<true>, dim3(tiles), dim3(THREADS), SMEM_BYTES, stream, V, P, D, first_col);
+    } else {
+        NSGP_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(nsgp_projector_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, SMEM_BYTES));
+        hipLaunchKernelGGL(nsgp_projector_kernel<false>, dim3(tiles), dim3(THREADS), SMEM_BYTES, stream, V, P, D, first_col);
+    }
+    NSGP_LAUNCH_CHECK();
+    if (normalise) {
+        const long n = (long)D * D;
+        int blocks = (int)std::min<long>(NORM_BLOCKS, (n + 255) / 256);
+        hipLaunchKernelGGL(nsgp_sumsq_partial_kernel, dim3(blocks), dim3(256), 0, stream, P, n, partial);
+        NSGP_LAUNCH_CHECK();
+        hipLaunchKernelGGL(nsgp_norm_final_kernel, dim3(1), dim3(256), 0, stream, partial, blocks);
+        NSGP_LAUNCH_CHECK();
+        hipLaunchKernelGGL(nsgp_divide_kernel, dim3(2048), dim3(256), 0, stream, P, n, partial);
+        NSGP_LAUNCH_CHECK();
+    }
+    return NSGP_OK;
+}

@@ -1,0 +1,158 @@
+"""Thin torch-tensor wrappers over the C ABI (device pointers + the current HIP stream).
+
+torch is plumbing here: device memory, streams.  All arithmetic runs in the HIP
+kernels of ``csrc/``.  Every wrapper raises on CPU tensors -- no fallback.
+"""
+import ctypes as C
+
+import torch
+
+from . import _lib
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _dev(t: torch.Tensor, name: str, dtype=torch.float32):
+    if not isinstance(t, torch.Tensor) or not t.is_cuda:
+        raise RuntimeError(f"nsgp_repre_amd: `{name}` must be a GPU tensor (there is no CPU fallback)")
+    if t.dtype != dtype:
+        raise TypeError(f"nsgp_repre_amd: `{name}` must be {dtype}, got {t.dtype}")
+    if not t.is_contiguous():
+        raise ValueError(f"nsgp_repre_amd: `{name}` must be contiguous")
+    return C.c_void_p(t.data_ptr())
+
+
+def project(a: torch.Tensor, proj: torch.Tensor, scale: float = 1.0, out: torch.Tensor = None,
+            accumulate: bool = False) -> torch.Tensor:
+    """``out (+)= scale * (a.view(rows, -1) @ proj)`` -- the `torch.mm(update.view(Cout,-1), P)` of
+    mmdet/engine/optimizers/SGD_NSCL.py:85-90 in isolation."""
+    lib = _lib.load_library()
+    rows = a.shape[0]
+    cols = a.numel() // rows
+    if proj.shape != (cols, cols):
+        raise ValueError(f"projector shape {tuple(proj.shape)} does not match update [{rows} x {cols}]")
+    if out is None:
+        out = torch.empty_like(a)
+    _lib.check(lib.nsgp_project(_dev(a, "a"), _dev(proj, "proj"), _dev(out, "out"), rows, cols, float(scale),
+                                int(accumulate), _stream()), "nsgp_project")
+    return out
+
+
+def build_projector(V: torch.Tensor, first_col: int, normalise: bool, out: torch.Tensor = None) -> torch.Tensor:
+    """``P = V[:, first_col:] @ V[:, first_col:].T`` (``/ ||P||_F`` if normalise) --
+    mmdet/engine/optimizers/SGD_NSCL.py:270-285."""
+    lib = _lib.load_library()
+    D = V.shape[0]
+    if V.shape != (D, D):
+        raise ValueError("V must be square")
+    if out is None:
+        out = torch.empty_like(V)
+    nbytes = lib.nsgp_projector_scratch_bytes(D)
+    scratch = torch.empty(nbytes, dtype=torch.uint8, device=V.device)
+    _lib.check(lib.nsgp_build_projector(_dev(V, "V"), D, int(first_col), int(bool(normalise)), _dev(out, "P"),
+                                        C.c_void_p(scratch.data_ptr()), nbytes, _stream()), "nsgp_build_projector")
+    return out
+
+
+def cov_accumulate_conv2d(x: torch.Tensor, kernel_size, stride, padding, cov: torch.Tensor = None,
+                          workspace: torch.Tensor = None) -> torch.Tensor:
+    """``C (+)= X^T X`` with X the implicit unfold of the batch mean --
+    mmdet/engine/runner/nsrunner_roi_replay.py:908-913, 930-934.  ``cov=None`` is the
+    reference's first call (assign); passing ``cov`` accumulates in place."""
+    lib = _lib.load_library()
+    B, cin, H, W = x.shape
+    kh, kw = kernel_size
+    sh, sw = stride
+    ph, pw = padding
+    D = cin * kh * kw
+    nbytes = lib.nsgp_cov_workspace_bytes(cin, H, W, kh, kw, sh, sw, ph, pw)
+    if nbytes == 0:
+        raise ValueError("bad convolution geometry")
+    if workspace is None or workspace.numel() * workspace.element_size() < nbytes:
+        workspace = torch.empty(nbytes, dtype=torch.uint8, device=x.device)
+    accumulate = cov is not None
+    if cov is None:
+        cov = torch.empty(D, D, dtype=torch.float32, device=x.device)
+    elif cov.shape != (D, D):
+        raise ValueError(f"cov shape {tuple(cov.shape)} != ({D},{D})")
+    _lib.check(lib.nsgp_cov_accumulate_conv2d(_dev(x, "x"), B, cin, H, W, kh, kw, sh, sw, ph, pw, _dev(cov, "cov"),
+                                              int(accumulate), C.c_void_p(workspace.data_ptr()),
+                                              workspace.numel() * workspace.element_size(), _stream()),
+               "nsgp_cov_accumulate_conv2d")
+    return cov
+
+
+def cov_workspace_bytes(cin, H, W, kernel_size, stride, padding) -> int:
+    lib = _lib.load_library()
+    return lib.nsgp_cov_workspace_bytes(cin, H, W, kernel_size[0], kernel_size[1], stride[0], stride[1],
+                                        padding[0], padding[1])
+
+
+def cov_accumulate_linear(x: torch.Tensor, cov: torch.Tensor = None) -> torch.Tensor:
+    """Linear branch, runner:901-902: ``X = mean(x, 0, keepdim)``; ``C (+)= X^T X``."""
+    lib = _lib.load_library()
+    if x.dim() != 2:
+        raise ValueError("linear covariance expects a [B x F] input (torch.mm in the reference needs 2-D)")
+    B, Fd = x.shape
+    accumulate = cov is not None
+    if cov is None:
+        cov = torch.empty(Fd, Fd, dtype=torch.float32, device=x.device)
+    _lib.check(lib.nsgp_cov_accumulate_linear(_dev(x, "x"), B, Fd, _dev(cov, "cov"), int(accumulate), _stream()),
+               "nsgp_cov_accumulate_linear")
+    return cov
+
+
+def sim_counts(feats: torch.Tensor, thr: float = 0.6):
+    """Row-normalised Gram >= thr -> (counts int64 [N], bitmask uint64-as-int64 [N x words]) --
+    mmdet/models/roi_heads/standard_roi_replay_head.py:417-423."""
+    lib = _lib.load_library()
+    N, D = feats.shape
+    words = (N + 63) // 64
+    norms = torch.empty(N, dtype=torch.float32, device=feats.device)
+    counts = torch.empty(N, dtype=torch.int64, device=feats.device)
+    bitmask = torch.empty(N, words, dtype=torch.int64, device=feats.device)
+    _lib.check(lib.repre_sim_counts(_dev(feats, "feats"), N, D, float(thr), _dev(norms, "norms"),
+                                    _dev(counts, "counts", torch.int64), _dev(bitmask, "bitmask", torch.int64),
+                                    _stream()), "repre_sim_counts")
+    return counts, bitmask
+
+
+def masked_mean(feats: torch.Tensor, rowmask_words: torch.Tensor = None, n_selected: int = None) -> torch.Tensor:
+    """Mean of the rows selected by a bit mask (int64 words) -> [1 x D] --
+    standard_roi_replay_head.py:413 (all rows) and :443 (``mean(F[m])``)."""
+    lib = _lib.load_library()
+    N, D = feats.shape
+    if rowmask_words is None:
+        n_selected = N
+        mptr = C.c_void_p(0)
+    else:
+        if n_selected is None:
+            raise ValueError("n_selected is required with a mask")
+        mptr = _dev(rowmask_words, "rowmask", torch.int64)
+    out = torch.empty(1, D, dtype=torch.float32, device=feats.device)
+    nbytes = lib.repre_masked_mean_workspace_bytes(N, D)
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=feats.device)
+    _lib.check(lib.repre_masked_mean(_dev(feats, "feats"), N, D, mptr, int(n_selected), _dev(out, "out"),
+                                     C.c_void_p(ws.data_ptr()), nbytes, _stream()), "repre_masked_mean")
+    return out
+
+
+def unpack_bitmask_row(words: torch.Tensor, n: int) -> torch.Tensor:
+    """int64 words (little-endian bit order) -> bool[n] (host-side glue for mask.pth)."""
+    w = words.cpu().numpy().view("uint64")
+    import numpy as np
+    bits = np.unpackbits(w.view(np.uint8), bitorder="little")[:n]
+    return torch.from_numpy(bits.astype(bool))
+
+
+def pack_bool_mask(mask: torch.Tensor) -> torch.Tensor:
+    """bool[n] -> int64 words, the inverse of unpack_bitmask_row."""
+    import numpy as np
+    m = mask.cpu().numpy().astype(np.uint8)
+    n = m.shape[0]
+    pad = (-n) % 64
+    if pad:
+        m = np.concatenate([m, np.zeros(pad, np.uint8)])
+    return torch.from_numpy(np.packbits(m, bitorder="little").view(np.int64).copy())

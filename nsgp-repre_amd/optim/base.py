@@ -1,0 +1,231 @@
+"""Common machinery of the four NSGP optimizers.
+
+Interface mirror of the reference's ``SGDNSCL`` / ``AdamWNSCL`` / ``AdamNSCL`` /
+``SGDNSCLNA`` (mmdet/engine/optimizers/*.py): ``torch.optim.Optimizer`` subclasses
+with the extra ``get_eigens`` / ``get_transforms`` / ``adaptive_threshold`` methods,
+the public ``eigens`` / ``transforms`` dicts and the extra param-group key
+``names`` (wired by the runner, nsrunner_roi_replay.py:473-484).
+
+What differs is *how* a step runs: instead of a Python loop of ~160 x 5 tiny
+elementwise launches plus 50 `torch.mm`, ``step()`` hands one table to
+``nsgp_plan_step`` (C ABI): one multi-tensor HIP kernel + one grouped fp32-MFMA
+GEMM on the current stream.
+"""
+import ctypes as C
+import logging
+from collections import defaultdict
+
+import numpy as np
+import torch
+from torch.optim.optimizer import Optimizer
+
+from .. import _lib, ops
+from .threshold import elbow_index
+
+logger = logging.getLogger("nsgp_repre_amd")
+
+
+class NSCLOptimizerBase(Optimizer):
+    _kind = _lib.NSGP_OPT_SGD   # which C-ABI update rule
+    _threshold_rule = "sgd"     # offset rule of adaptive_threshold
+    _normalise_all = False      # Adam_NSCL.py:183 normalises every projector
+
+    def __init__(self, params, defaults):
+        super().__init__(params, defaults)
+        self.eigens = defaultdict(dict)
+        self.transforms = defaultdict(dict)
+        self.count = 0
+        #: mirror the reference's in-place mutation of ``p.grad`` (weight decay / Nesterov add)
+        self.mutate_grad = True
+        self._plans = []
+        self._plan_key = None
+        self._workspaces = []
+
+    def __setstate__(self, state):
+        super().__setstate__(state)
+        for group in self.param_groups:
+            group.setdefault("svd", False)
+            group.setdefault("names", [])
+        self._plans, self._plan_key, self._workspaces = [], None, []
+
+    def __del__(self):
+        try:
+            self._destroy_plans()
+        except Exception:
+            pass
+
+    # ------------------------------------------------------------------ spectrum -> projector
+    def adaptive_threshold(self, svals: torch.Tensor, offset: float = 0):
+        """Bool mask [D], True from the elbow index on (the small-sigma tail that spans the
+        null space).  Host-side like the reference (SGD_NSCL.py:98-177: numpy + scipy)."""
+        i_thres = elbow_index(svals.detach().cpu().numpy(), offset, self._threshold_rule)
+        mask = torch.zeros(svals.shape[0], dtype=torch.bool, device=svals.device)
+        mask[i_thres:] = True
+        return mask
+
+    def _svd_named(self):
+        for group in self.param_groups:
+            if group["svd"] is False:
+                continue
+            for n, p in zip(group["names"], group["params"]):
+                yield group, n, p
+
+    def get_eigens(self, fea_in, distinguisher=None):
+        """Spectrum of every covariance present in ``fea_in`` (SGD_NSCL.py:360-380 runs
+        ``torch.svd(C, some=False)``).  C is symmetric PSD, so its SVD is its
+        eigendecomposition: ``eigh`` (rocSOLVER on the GPU) gives the same singular values
+        (|lambda|, sorted descending) and right singular vectors up to sign -- and the
+        projector built from them is sign-invariant."""
+        for _, n, _p in self._svd_named():
+            if n not in fea_in.keys():
+                continue
+            cov = fea_in[n]
+            lam, Q = torch.linalg.eigh(cov)
+            s = lam.abs()
+            order = torch.argsort(s, descending=True, stable=True)
+            eigen = self.eigens[n]
+            eigen["eigen_value"] = s[order].contiguous()
+            eigen["eigen_vector"] = Q[:, order].contiguous()
+
+    def _null_space_start(self, group, n):
+        """Index of the first basis column kept (the mask is always a suffix)."""
+        mask = self.adaptive_threshold(self.eigens[n]["eigen_value"], offset=self._offset)
+        return int(mask.to(torch.int8).argmax().item())
+
+    def _normalise(self, n):
+        return self._normalise_all or ("backbone" in n)
+
+    def get_transforms(self, offset=0.0):
+        """P = V_tail V_tail^T (/ ||P||_F for backbone layers) per named parameter
+        (SGD_NSCL.py:203-290), built by the HIP SYRK kernel ``nsgp_build_projector``."""
+        self._offset = offset
+        for group, n, _p in self._svd_named():
+            if n not in self.eigens.keys():
+                logger.info("missing keys: %s", n)
+                continue
+            sv = self.eigens[n]["eigen_value"]
+            first = self._null_space_start(group, n)
+            kept = sv.shape[0] - first
+            logger.info("%s: reserving basis %d/%d; cond: %s, radio:%s", n, kept, sv.shape[0],
+                        float(sv[0] / sv[first]), float(sv[first:].sum() / sv.sum()))
+            V = self.eigens[n]["eigen_vector"]
+            self.transforms[n] = ops.build_projector(V, first, self._normalise(n)).detach_()
+        self._plan_key = None  # new projector buffers -> new plan
+
+    # ------------------------------------------------------------------ step
+    def _init_state(self, p, state, group):
+        raise NotImplementedError
+
+    def _state_tensors(self, state, group):
+        raise NotImplementedError
+
+    def _fill_hyper(self, h, group, step):
+        raise NotImplementedError
+
+    def _destroy_plans(self):
+        if self._plans:
+            lib = _lib.load_library()
+            for plan in self._plans:
+                lib.nsgp_plan_destroy(plan["handle"])
+        self._plans = []
+        self._workspaces = []
+
+    def _build_plans(self, entries):
+        """entries: list of (group_index, name, p, state).  One plan per <= NSGP_MAX_HYPER groups."""
+        lib = _lib.load_library()
+        self._destroy_plans()
+        groups = sorted({gi for gi, *_ in entries})
+        for lo in range(0, len(groups), _lib.NSGP_MAX_HYPER):
+            gset = groups[lo:lo + _lib.NSGP_MAX_HYPER]
+            slot = {gi: k for k, gi in enumerate(gset)}
+            sub = [e for e in entries if e[0] in slot]
+            descs = (_lib.TensorDesc * len(sub))()
+            for d, (gi, n, p, st) in zip(descs, sub):
+                group = self.param_groups[gi]
+                s0, s1, s2 = self._state_tensors(st, group)
+                d.param = p.data.data_ptr()
+                d.state0 = s0.data_ptr()
+                d.state1 = s1.data_ptr() if s1 is not None else None
+                d.state2 = s2.data_ptr() if s2 is not None else None
+                d.numel = p.numel()
+                d.hyper = slot[gi]
+                P = self.transforms.get(n) if (group["svd"] and len(self.transforms) > 0 and n in self.transforms.keys()) else None
+                if P is not None:
+                    if p.dim() not in (2, 4):
+                        raise RuntimeError(f"{n}: projected parameters must be 2-D or 4-D (SGD_NSCL.py:83-90)")
+                    rows = p.shape[0]
+                    cols = p.numel() // rows
+                    if tuple(P.shape) != (cols, cols) or not P.is_cuda or P.dtype != torch.float32 or not P.is_contiguous():
+                        raise RuntimeError(f"{n}: transform must be a contiguous fp32 GPU [{cols}x{cols}] tensor, got "
+                                           f"{tuple(P.shape)} {P.dtype} {P.device}")
+                    d.proj = P.data_ptr()
+                    d.rows, d.cols = rows, cols
+                else:
+                    d.proj = None
+            nbytes = lib.nsgp_plan_workspace_bytes(descs, len(sub), self._kind)
+            ws = torch.empty(max(nbytes, 1), dtype=torch.uint8, device=sub[0][2].device)
+            handle = C.c_void_p()
+            _lib.check(lib.nsgp_plan_create(C.byref(handle), descs, len(sub), self._kind,
+                                            C.c_void_p(ws.data_ptr()), nbytes), "nsgp_plan_create")
+            self._workspaces.append(ws)
+            self._plans.append(dict(handle=handle, entries=sub, groups=gset,
+                                    grads=(C.c_void_p * len(sub))(), hyper=(_lib.Hyper * len(gset))()))
+
+    def plan_stats(self):
+        """(gemm_flops, algorithmic_bytes, n_tiles, n_projected) summed over the current plans."""
+        lib = _lib.load_library()
+        tot = [0.0, 0.0, 0, 0]
+        for plan in self._plans:
+            f, b, t, n = C.c_double(), C.c_double(), C.c_int(), C.c_int()
+            _lib.check(lib.nsgp_plan_stats(plan["handle"], C.byref(f), C.byref(b), C.byref(t), C.byref(n)))
+            tot = [tot[0] + f.value, tot[1] + b.value, tot[2] + t.value, tot[3] + n.value]
+        return tuple(tot)
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        """One optimization step (SGD_NSCL.py:59-96 semantics, every listed (name, p) pair)."""
+        loss = None
+        if closure is not None:
+            with torch.enable_grad():
+                loss = closure()
+        lib = _lib.load_library()
+        entries, key = [], []
+        for gi, group in enumerate(self.param_groups):
+            for n, p in zip(group["names"], group["params"]):
+                if p.grad is None:  # the reference dereferences p.grad.data unconditionally (:75)
+                    raise AttributeError(f"{n}: 'NoneType' object has no attribute 'data' (parameter has no grad)")
+                if p.grad.is_sparse:
+                    raise RuntimeError("Adam does not support sparse gradients, please consider SparseAdam instead")
+                if not p.is_cuda:
+                    raise RuntimeError(f"{n}: nsgp_repre_amd optimizers run on the GPU only (no CPU fallback)")
+                if p.dtype != torch.float32 or p.grad.dtype != torch.float32:
+                    raise TypeError(f"{n}: parameters and gradients must be fp32")
+                if not p.is_contiguous() or not p.grad.is_contiguous():
+                    raise RuntimeError(f"{n}: parameter/gradient must be contiguous")
+                state = self.state[p]
+                if len(state) == 0:
+                    self._init_state(p, state, group)
+                state["step"] += 1
+                entries.append((gi, n, p, state))
+                P = self.transforms.get(n) if n in self.transforms.keys() else None
+                key.append((p.data_ptr(), gi, P.data_ptr() if isinstance(P, torch.Tensor) else 0, bool(group["svd"])))
+        if not entries:
+            return loss
+        key = tuple(key)
+        if key != self._plan_key:
+            self._build_plans(entries)
+            self._plan_key = key
+        stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+        for plan in self._plans:
+            steps = defaultdict(set)
+            for i, (gi, n, p, st) in enumerate(plan["entries"]):
+                plan["grads"][i] = p.grad.data_ptr()
+                steps[gi].add(st["step"])
+            for k, gi in enumerate(plan["groups"]):
+                if len(steps[gi]) != 1:
+                    raise RuntimeError("parameters of one param group carry different step counts")
+                self._fill_hyper(plan["hyper"][k], self.param_groups[gi], next(iter(steps[gi])))
+                plan["hyper"][k].write_grad = int(self.mutate_grad)
+            _lib.check(lib.nsgp_plan_step(plan["handle"], plan["grads"], plan["hyper"], len(plan["groups"]), stream),
+                       "nsgp_plan_step")
+        return loss
