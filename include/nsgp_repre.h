@@ -112,6 +112,12 @@ int nsgp_plan_step(nsgp_plan_t* plan, float* const* grads, const nsgp_hyper_t* h
 int nsgp_plan_stats(const nsgp_plan_t* plan, double* gemm_flops, double* algorithmic_bytes,
                     int* n_tiles, int* n_projected);
 
+/* Per-launch timing with HIP events recorded on the launch stream (measurement only): between
+ * _begin and _end each nsgp_plan_step records 3 events; _end synchronises on them and returns
+ * the average duration of the elementwise launch and of the projection-GEMM launch(es). */
+int nsgp_plan_profile_begin(nsgp_plan_t* plan, int max_steps);
+int nsgp_plan_profile_end(nsgp_plan_t* plan, int* n_steps, float* update_ms_avg, float* gemm_ms_avg);
+
 /* Stand-alone projection `out[rows x cols] (+)= scale * (a[rows x cols] @ proj[cols x cols])`
  * (SGD_NSCL.py:85-90 in isolation; accumulate=0 overwrites `out`).  Used by tests to check
  * the projected update itself at 1e-5 rel, which p += update cannot resolve in fp32. */

@@ -38,6 +38,8 @@ SIGNATURES = {
     "nsgp_plan_destroy": (C.c_int, [C.c_void_p]),
     "nsgp_plan_step": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(Hyper), C.c_int, C.c_void_p]),
     "nsgp_plan_stats": (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    "nsgp_plan_profile_begin": (C.c_int, [C.c_void_p, C.c_int]),
+    "nsgp_plan_profile_end": (C.c_int, [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_float), C.POINTER(C.c_float)]),
     "nsgp_project": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_int, C.c_void_p]),
     "nsgp_cov_workspace_bytes": (C.c_size_t, [C.c_int] * 9),
     "nsgp_cov_accumulate_conv2d": (C.c_int, [C.c_void_p] + [C.c_int] * 10 + [C.c_void_p, C.c_int, C.c_void_p, C.c_size_t, C.c_void_p]),

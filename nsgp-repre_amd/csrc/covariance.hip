@@ -54,7 +54,7 @@ __device__ __forceinline__ void stage_im2col(const float* __restrict__ xm, const
 #pragma unroll
     for (int j = 0; j < 4; ++j)
 #pragma unroll
-        for (int e = 0; e < 4; ++e) r[j][e] = (rowbase[j] >= 0 && off[e] >= 0) ? xm[rowbase[j] + off[e]] : 0.0f;
+        for (int e = 0; e < 4; ++e) r[j][e] = (rowbase[j] >= 0 && off[e] >= 0) ? as_global(xm)[rowbase[j] + off[e]] : 0.0f;
 }
 
 __device__ __forceinline__ void im2col_rowbase(const ConvGeom& g, int d0, long (&rowbase)[4]) {
@@ -88,28 +88,15 @@ __global__ __launch_bounds__(256, 2) void nsgp_cov_syrk_kernel(const float* __re
     long base_a[4], base_b[4];
     im2col_rowbase(g, m0, base_a);
     im2col_rowbase(g, n0, base_b);
-    float ra[4][4], rb[4][4];
-    const int nk = (l_end - l_beg + BK - 1) / BK;
-    if (nk > 0) {
-        stage_im2col(xm, base_a, g, l_beg, l_end, ra);
-        stage_im2col(xm, base_b, g, l_beg, l_end, rb);
-        write_rows_noscale(a_img(smem, 0), ra);
-        write_rows_noscale(b_img(smem, 0), rb);
-    }
-    __syncthreads();
-    for (int t = 0; t < nk; ++t) {
-        const int cur = t & 1;
-        if (t + 1 < nk) {
-            stage_im2col(xm, base_a, g, l_beg + (t + 1) * BK, l_end, ra);
-            stage_im2col(xm, base_b, g, l_beg + (t + 1) * BK, l_end, rb);
-        }
-        mfma_kstep<true>(a_img(smem, cur), b_img(smem, cur), acc, wm, wn);
-        if (t + 1 < nk) {
-            write_rows_noscale(a_img(smem, cur ^ 1), ra);
-            write_rows_noscale(b_img(smem, cur ^ 1), rb);
-        }
-        __syncthreads();
-    }
+    float ra[2][4][4], rb[2][4][4];
+    mfma_pipeline<true>(
+        (l_end - l_beg + BK - 1) / BK, smem, acc,
+        [&](int t, auto s) {
+            stage_im2col(xm, base_a, g, l_beg + t * BK, l_end, ra[decltype(s)::value]);
+            stage_im2col(xm, base_b, g, l_beg + t * BK, l_end, rb[decltype(s)::value]);
+        },
+        [&](float* img, int, auto s) { write_rows_noscale(img, ra[decltype(s)::value]); },
+        [&](float* img, int, auto s) { write_rows_noscale(img, rb[decltype(s)::value]); });
     float* out = partial + (long)blockIdx.y * g.D * g.D;
 #pragma unroll
     for (int mi = 0; mi < 2; ++mi)
@@ -119,7 +106,7 @@ __global__ __launch_bounds__(256, 2) void nsgp_cov_syrk_kernel(const float* __re
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int row = m0 + wm * 64 + mi * 32 + acc_row(r, lane);
-                if (row < g.D && col < g.D) out[(long)row * g.D + col] = acc[mi][ni][r];
+                if (row < g.D && col < g.D) as_global(out)[(long)row * g.D + col] = acc[mi][ni][r];
             }
         }
 }

@@ -30,6 +30,16 @@ constexpr int KN_IMG = BK * BN;                      // floats
 constexpr int SMEM_FLOATS = 2 * ROW_IMG + 2 * ROW_IMG;
 constexpr int SMEM_BYTES = SMEM_FLOATS * 4;          // 67,584 B -> 2 workgroups / CU
 
+// Two workgroups share a CU (one wave of each per SIMD).  With equal priority they split the MFMA
+// pipe evenly, advance in lockstep and reach their barrier/staging phases together, leaving the
+// pipe idle.  Giving the co-resident workgroups different issue priorities breaks the symmetry:
+// the favoured one runs at full rate and the other fills its gaps.  HW_REG_HW_ID.TG_ID (bits
+// 19:16) numbers the workgroups resident on this CU; speed only, never correctness.
+__device__ __forceinline__ void stagger_priority_by_cu_slot() {
+    const unsigned tg = __builtin_amdgcn_s_getreg((3 << 11) | (16 << 6) | 4);
+    if (tg & 1u) __builtin_amdgcn_s_setprio(2);
+}
+
 __device__ __forceinline__ float* a_img(float* smem, int i) { return smem + i * ROW_IMG; }
 __device__ __forceinline__ float* b_img(float* smem, int i) { return smem + (2 + i) * ROW_IMG; }
 
@@ -37,16 +47,26 @@ __device__ __forceinline__ float* b_img(float* smem, int i) { return smem + (2 +
 // Row-image operand: thread t stages rows (t>>3)+32*j, j=0..3, k = (t&7)*4 .. +3.
 // KN-image operand:  thread t stages k rows (t>>5)+8*j, n = (t&31)*4 .. +3.
 
+// Pointers that reach a kernel through a table in memory are "generic" to the compiler and would
+// be accessed with flat_load/flat_store (which tick BOTH vmcnt and lgkmcnt and so serialise against
+// the LDS pipeline).  Everything here is hipMalloc'ed global memory: say so.
+typedef __attribute__((address_space(1))) float gfloat;
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(1))) f32x4 gf32x4;
+__device__ __forceinline__ const gfloat* as_global(const float* p) { return (const gfloat*)p; }
+__device__ __forceinline__ gfloat* as_global(float* p) { return (gfloat*)p; }
+
 template <bool FAST>
 __device__ __forceinline__ void fetch4(const float* __restrict__ base, long ld, int n_rows, int n_cols,
                                        int row, int col, float (&v)[4]) {
     if (FAST) {
-        const float4 q = *reinterpret_cast<const float4*>(base + (long)row * ld + col);
-        v[0] = q.x; v[1] = q.y; v[2] = q.z; v[3] = q.w;
+        const f32x4 q = *(const gf32x4*)(base + (long)row * ld + col);
+        v[0] = q[0]; v[1] = q[1]; v[2] = q[2]; v[3] = q[3];
     } else {
+        const gfloat* g = as_global(base);
 #pragma unroll
         for (int e = 0; e < 4; ++e)
-            v[e] = (row < n_rows && col + e < n_cols) ? base[(long)row * ld + col + e] : 0.0f;
+            v[e] = (row < n_rows && col + e < n_cols) ? g[(long)row * ld + col + e] : 0.0f;
     }
 }
 
@@ -98,7 +118,7 @@ __device__ __forceinline__ void write_kn(float* __restrict__ img, const float (&
 // ---- one K-step of MFMAs for this wave's 64x64 sub-tile --------------------
 // A operand of v_mfma_f32_32x32x2_f32: lane l holds A[i = l&31][k = l>>5];
 // B operand: lane l holds B[k = l>>5][j = l&31].
-template <bool B_ROWS>
+template <bool B_ROWS, int KK0 = 0, int KK1 = BK>
 __device__ __forceinline__ void mfma_kstep(const float* __restrict__ As, const float* __restrict__ Bs,
                                            f32x16 (&acc)[2][2], int wm, int wn) {
     const int lane = threadIdx.x & 63;
@@ -106,7 +126,7 @@ __device__ __forceinline__ void mfma_kstep(const float* __restrict__ As, const f
     const float* a_base = As + (wm * 64 + r) * ROW_LD + h;
     const float* b_base = B_ROWS ? (Bs + (wn * 64 + r) * ROW_LD + h) : (Bs + h * BN + wn * 64 + r);
 #pragma unroll
-    for (int kk = 0; kk < BK; kk += 2) {
+    for (int kk = KK0; kk < KK1; kk += 2) {
         const float a0 = a_base[kk];
         const float a1 = a_base[32 * ROW_LD + kk];
         float b0, b1;
@@ -162,38 +182,91 @@ __device__ __forceinline__ void write_rows_klo(float* __restrict__ img, const fl
 // ---- generic dense tile: acc = (scale*A[m0.., :]) x B ------------------------
 // A: [M x K] row-major (lda).  B_ROWS=false: B is [K x N] row-major (ldb), n contiguous.
 // B_ROWS=true: B is given as [N x K] row-major (ldb), i.e. acc = A x B^T.
+// ---- the software pipeline shared by every MFMA kernel ------------------------------------
+// Two register sets and two LDS buffers.  K-step t (reads LDS buffer t%2):
+//     issue the global loads of tile t+2 into register set t%2       (pinned ABOVE the MFMAs)
+//     32 MFMAs
+//     LDS-write tile t+1's A image from register set (t+1)%2          (loaded during step t-1)
+//     16 MFMAs, LDS-write tile t+1's B image, 16 MFMAs, barrier
+// so every global load has a full K-step (>= 4096 MFMA cycles) to land before its first use.
+//
+// Why the pins: left alone, hipcc sinks each global load down to its first use and emits
+// `load; s_waitcnt vmcnt(0); ds_write` eight times per K-step -- the whole memory latency,
+// serially, with the MFMA pipe idle (measured on 4096^3: 72 TF at one workgroup per CU, 105 at
+// two, against 147 for the same loop without staging).  The masked sched_barriers only forbid
+// VMEM reads and MFMAs from crossing the first pin and VALU / DS writes from crossing the
+// others; LDS reads and SALU still move freely.  RB is a template constant so LDS reads and
+// writes are provably disjoint ranges and register sets are statically indexed.
+constexpr int SCHED_PIN_VMEM_READ = 0x2 | 0x4 | 0x100;   // VALU, SALU, DS-read may cross
+constexpr int SCHED_PIN_STAGING = 0x4 | 0x8 | 0x100;     // SALU, MFMA, DS-read may cross
+
+template <int I>
+struct IC {
+    static constexpr int value = I;
+};
+
+template <bool B_ROWS, int RB, class LoadF, class WriteAF, class WriteBF>
+__device__ __forceinline__ void kstep_pipelined(float* smem, f32x16 (&acc)[2][2], int wm, int wn, int t_load,
+                                                int t_write, LoadF load, WriteAF write_a, WriteBF write_b) {
+    load(t_load, IC<RB>{});
+    __builtin_amdgcn_sched_barrier(SCHED_PIN_VMEM_READ);
+    const float* Ar = smem + RB * ROW_IMG;
+    const float* Br = smem + (2 + RB) * ROW_IMG;
+    mfma_kstep<B_ROWS, 0, BK / 2>(Ar, Br, acc, wm, wn);
+    __builtin_amdgcn_sched_barrier(SCHED_PIN_STAGING);
+    write_a(smem + (1 - RB) * ROW_IMG, t_write, IC<1 - RB>{});
+    mfma_kstep<B_ROWS, BK / 2, 3 * BK / 4>(Ar, Br, acc, wm, wn);
+    __builtin_amdgcn_sched_barrier(SCHED_PIN_STAGING);
+    write_b(smem + (3 - RB) * ROW_IMG, t_write, IC<1 - RB>{});
+    mfma_kstep<B_ROWS, 3 * BK / 4, BK>(Ar, Br, acc, wm, wn);
+    __syncthreads();
+}
+
+// Drives `nk` K-steps.  load(t, IC<S>) fetches the operands of K-step t into the caller's register
+// set S; write_a(img, t, IC<S>) / write_b(...) store set S into the given LDS image.  Tile indices
+// past the end are clamped to nk-1 (two redundant, in-bounds tile loads per output tile) so the
+// loop body is branch-free.
+template <bool B_ROWS, class LoadF, class WriteAF, class WriteBF>
+__device__ __forceinline__ void mfma_pipeline(int nk, float* smem, f32x16 (&acc)[2][2], LoadF load, WriteAF write_a,
+                                              WriteBF write_b) {
+    const int wave = threadIdx.x >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    if (nk <= 0) return;
+    const int last = nk - 1;
+    load(0, IC<0>{});
+    write_a(a_img(smem, 0), 0, IC<0>{});
+    write_b(b_img(smem, 0), 0, IC<0>{});
+    load(min(1, last), IC<1>{});
+    __syncthreads();
+    int t = 0;
+    for (; t + 1 < nk; t += 2) {
+        kstep_pipelined<B_ROWS, 0>(smem, acc, wm, wn, min(t + 2, last), min(t + 1, last), load, write_a, write_b);
+        kstep_pipelined<B_ROWS, 1>(smem, acc, wm, wn, min(t + 3, last), min(t + 2, last), load, write_a, write_b);
+    }
+    if (t < nk) kstep_pipelined<B_ROWS, 0>(smem, acc, wm, wn, last, last, load, write_a, write_b);
+}
+
+// ---- generic dense tile: acc = (scale*A[m0.., :]) x B ------------------------
+// A: [M x K] row-major (lda).  B_ROWS=false: B is [K x N] row-major (ldb), n contiguous.
+// B_ROWS=true: B is given as [N x K] row-major (ldb), i.e. acc = A x B^T.
 template <bool FAST_A, bool FAST_B, bool B_ROWS>
 __device__ __forceinline__ void gemm_tile(const float* __restrict__ A, long lda, const float* __restrict__ B,
                                           long ldb, int M, int N, int K, int m0, int n0, float a_scale,
                                           float* smem, f32x16 (&acc)[2][2]) {
-    const int wave = threadIdx.x >> 6;
-    const int wm = wave >> 1, wn = wave & 1;
-    float ra[4][4], rb[4][4];
-    const int nk = (K + BK - 1) / BK;
-
-    stage_rows<FAST_A>(A, lda, M, K, m0, 0, ra);
-    if (B_ROWS) stage_rows<FAST_B>(B, ldb, N, K, n0, 0, rb);
-    else stage_kn<FAST_B>(B, ldb, K, N, 0, n0, rb);
-    write_rows(a_img(smem, 0), ra, a_scale);
-    if (B_ROWS) write_rows_noscale(b_img(smem, 0), rb);
-    else write_kn(b_img(smem, 0), rb);
-    __syncthreads();
-
-    for (int t = 0; t < nk; ++t) {
-        const int cur = t & 1;
-        if (t + 1 < nk) {
-            stage_rows<FAST_A>(A, lda, M, K, m0, (t + 1) * BK, ra);
-            if (B_ROWS) stage_rows<FAST_B>(B, ldb, N, K, n0, (t + 1) * BK, rb);
-            else stage_kn<FAST_B>(B, ldb, K, N, (t + 1) * BK, n0, rb);
-        }
-        mfma_kstep<B_ROWS>(a_img(smem, cur), b_img(smem, cur), acc, wm, wn);
-        if (t + 1 < nk) {
-            write_rows(a_img(smem, cur ^ 1), ra, a_scale);
-            if (B_ROWS) write_rows_noscale(b_img(smem, cur ^ 1), rb);
-            else write_kn(b_img(smem, cur ^ 1), rb);
-        }
-        __syncthreads();
-    }
+    float ra[2][4][4], rb[2][4][4];
+    mfma_pipeline<B_ROWS>(
+        (K + BK - 1) / BK, smem, acc,
+        [&](int t, auto s) {
+            constexpr int S = decltype(s)::value;
+            stage_rows<FAST_A>(A, lda, M, K, m0, t * BK, ra[S]);
+            if (B_ROWS) stage_rows<FAST_B>(B, ldb, N, K, n0, t * BK, rb[S]);
+            else stage_kn<FAST_B>(B, ldb, K, N, t * BK, n0, rb[S]);
+        },
+        [&](float* img, int, auto s) { write_rows(img, ra[decltype(s)::value], a_scale); },
+        [&](float* img, int, auto s) {
+            if (B_ROWS) write_rows_noscale(img, rb[decltype(s)::value]);
+            else write_kn(img, rb[decltype(s)::value]);
+        });
 }
 
 }  // namespace nsgp

@@ -15,11 +15,19 @@
 //           that share a P column panel land on the same XCD (blockIdx % 8).
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <new>
 #include <vector>
 
 #include "common.hpp"
 #include "gemm_core.hpp"
+
+#ifndef NSGP_STAGGER
+#define NSGP_STAGGER 0
+#endif
+#ifndef NSGP_ASSUME_ALIGNED
+#define NSGP_ASSUME_ALIGNED 0
+#endif
 
 namespace nsgp {
 
@@ -187,7 +195,7 @@ __device__ __forceinline__ void store_tile(float* __restrict__ C, long ldc, int 
             for (int r = 0; r < 16; ++r) {
                 const int row = m0 + wm * 64 + mi * 32 + acc_row(r, lane);
                 if (FAST || (row < M && col < N)) {
-                    float* dst = C + (long)row * ldc + col;
+                    gfloat* dst = as_global(C) + (long)row * ldc + col;
                     *dst = ACCUM ? (*dst + acc[mi][ni][r]) : acc[mi][ni][r];
                 }
             }
@@ -199,6 +207,7 @@ __global__ __launch_bounds__(256, 2) void nsgp_project_kernel(const TileDev* __r
                                                               const LayerDev* __restrict__ layers,
                                                               const DynBlock* __restrict__ dyn) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
+    if (NSGP_STAGGER) stagger_priority_by_cu_slot();
     const TileDev t = tiles[blockIdx.x];
     const LayerDev L = layers[t.layer];
     const float* A;
@@ -217,7 +226,7 @@ __global__ __launch_bounds__(256, 2) void nsgp_project_kernel(const TileDev* __r
     zero_acc(acc);
     // the grad pointer is only known at step time: a misaligned one (e.g. a view into a flat
     // bucket) takes the guarded scalar loader for the A operand only
-    if (!FAST || ((uintptr_t)A & 15u) == 0)
+    if (!FAST || NSGP_ASSUME_ALIGNED || ((uintptr_t)A & 15u) == 0)
         gemm_tile<FAST, FAST, false>(A, L.cols, L.proj, L.cols, L.rows, L.cols, L.cols, t.m0, t.n0, scale, smem, acc);
     else
         gemm_tile<false, true, false>(A, L.cols, L.proj, L.cols, L.rows, L.cols, L.cols, t.m0, t.n0, scale, smem, acc);
@@ -267,6 +276,9 @@ struct nsgp_plan {
     hipEvent_t ev[NSLOT] = {nullptr, nullptr, nullptr, nullptr};
     bool ev_used[NSLOT] = {false, false, false, false};
     int slot = 0;
+    // optional per-launch timing: 3 events per recorded step (before update, between, after GEMM)
+    std::vector<hipEvent_t> prof_ev;
+    int prof_cap = 0, prof_n = 0;
 };
 
 static bool tensor_fast(const nsgp_tensor_t& t) {
@@ -339,13 +351,23 @@ extern "C" int nsgp_plan_create(nsgp_plan_t** out, const nsgp_tensor_t* tensors,
             while (g1 < order.size() && ld[order[g1]].cols == ld[order[g0]].cols) ++g1;
             std::vector<TileDev> q[8];
             int rot = 0;
+            const char* ord_env = getenv("NSGP_TILE_ORDER");  // measurement knob: 0 = XCD queues (default)
+            const int ord = ord_env ? atoi(ord_env) : 0;
             for (size_t oi = g0; oi < g1; ++oi) {
                 const int li = order[oi];
                 if ((layer_fast[li] != 0) != (pass == 0)) continue;
                 const int mb = (ld[li].rows + BM - 1) / BM, nb = (ld[li].cols + BN - 1) / BN;
-                for (int j = 0; j < nb; ++j)
-                    for (int m = 0; m < mb; ++m) q[(j + rot) & 7].push_back(TileDev{li, m * BM, j * BN, 0});
-                rot += nb;
+                if (ord == 1) {         // plain: n fastest
+                    for (int m = 0; m < mb; ++m)
+                        for (int j = 0; j < nb; ++j) dst.push_back(TileDev{li, m * BM, j * BN, 0});
+                } else if (ord == 2) {  // plain: m fastest
+                    for (int j = 0; j < nb; ++j)
+                        for (int m = 0; m < mb; ++m) dst.push_back(TileDev{li, m * BM, j * BN, 0});
+                } else {
+                    for (int j = 0; j < nb; ++j)
+                        for (int m = 0; m < mb; ++m) q[(j + rot) & 7].push_back(TileDev{li, m * BM, j * BN, 0});
+                    rot += nb;
+                }
             }
             size_t pos[8] = {0, 0, 0, 0, 0, 0, 0, 0};
             size_t total = 0;
@@ -423,6 +445,7 @@ extern "C" int nsgp_plan_destroy(nsgp_plan_t* P) {
         if (P->h_dyn[s]) (void)hipHostFree(P->h_dyn[s]);
         if (P->d_dyn[s]) (void)hipFree(P->d_dyn[s]);
     }
+    for (hipEvent_t e : P->prof_ev) (void)hipEventDestroy(e);
     if (P->d_tensors) (void)hipFree(P->d_tensors);
     if (P->d_layers) (void)hipFree(P->d_layers);
     if (P->d_tiles) (void)hipFree(P->d_tiles);
@@ -457,12 +480,15 @@ extern "C" int nsgp_plan_step(nsgp_plan_t* P, float* const* grads, const nsgp_hy
     std::memcpy(h->grads, grads, sizeof(float*) * (size_t)P->n_tensors);
     NSGP_HIP(hipMemcpyAsync(P->d_dyn[s], P->h_dyn[s], P->dyn_bytes, hipMemcpyHostToDevice, stream));
     const DynBlock* d = reinterpret_cast<const DynBlock*>(P->d_dyn[s]);
+    const bool prof = P->prof_n < P->prof_cap;
+    if (prof) NSGP_HIP(hipEventRecord(P->prof_ev[3 * P->prof_n + 0], stream));
 
     if (P->optimizer == NSGP_OPT_SGD)
         hipLaunchKernelGGL(nsgp_update_kernel<NSGP_OPT_SGD>, dim3(P->n_chunks), dim3(256), 0, stream, P->d_chunks, P->d_tensors, d);
     else
         hipLaunchKernelGGL(nsgp_update_kernel<NSGP_OPT_ADAM>, dim3(P->n_chunks), dim3(256), 0, stream, P->d_chunks, P->d_tensors, d);
     NSGP_LAUNCH_CHECK();
+    if (prof) NSGP_HIP(hipEventRecord(P->prof_ev[3 * P->prof_n + 1], stream));
     if (P->n_tiles_fast > 0) {
         if (P->optimizer == NSGP_OPT_SGD)
             hipLaunchKernelGGL((nsgp_project_kernel<NSGP_OPT_SGD, true>), dim3(P->n_tiles_fast), dim3(THREADS), SMEM_BYTES, stream, P->d_tiles, P->d_layers, d);
@@ -478,8 +504,43 @@ extern "C" int nsgp_plan_step(nsgp_plan_t* P, float* const* grads, const nsgp_hy
             hipLaunchKernelGGL((nsgp_project_kernel<NSGP_OPT_ADAM, false>), dim3(P->n_tiles_generic), dim3(THREADS), SMEM_BYTES, stream, gt, P->d_layers, d);
         NSGP_LAUNCH_CHECK();
     }
+    if (prof) {
+        NSGP_HIP(hipEventRecord(P->prof_ev[3 * P->prof_n + 2], stream));
+        ++P->prof_n;
+    }
     NSGP_HIP(hipEventRecord(P->ev[s], stream));
     P->ev_used[s] = true;
+    return NSGP_OK;
+}
+
+extern "C" int nsgp_plan_profile_begin(nsgp_plan_t* P, int max_steps) {
+    if (!P || max_steps < 0 || max_steps > 4096) return fail(NSGP_ERR_INVALID, "nsgp_plan_profile_begin: bad argument");
+    while ((int)P->prof_ev.size() < 3 * max_steps) {
+        hipEvent_t e;
+        NSGP_HIP(hipEventCreate(&e));
+        P->prof_ev.push_back(e);
+    }
+    P->prof_cap = max_steps;
+    P->prof_n = 0;
+    return NSGP_OK;
+}
+
+extern "C" int nsgp_plan_profile_end(nsgp_plan_t* P, int* n_steps, float* update_ms_avg, float* gemm_ms_avg) {
+    if (!P) return fail(NSGP_ERR_INVALID, "nsgp_plan_profile_end: null plan");
+    double u = 0, g = 0;
+    for (int i = 0; i < P->prof_n; ++i) {
+        NSGP_HIP(hipEventSynchronize(P->prof_ev[3 * i + 2]));
+        float a = 0, b = 0;
+        NSGP_HIP(hipEventElapsedTime(&a, P->prof_ev[3 * i + 0], P->prof_ev[3 * i + 1]));
+        NSGP_HIP(hipEventElapsedTime(&b, P->prof_ev[3 * i + 1], P->prof_ev[3 * i + 2]));
+        u += a;
+        g += b;
+    }
+    if (n_steps) *n_steps = P->prof_n;
+    if (update_ms_avg) *update_ms_avg = P->prof_n ? (float)(u / P->prof_n) : 0.0f;
+    if (gemm_ms_avg) *gemm_ms_avg = P->prof_n ? (float)(g / P->prof_n) : 0.0f;
+    P->prof_cap = 0;
+    P->prof_n = 0;
     return NSGP_OK;
 }
 

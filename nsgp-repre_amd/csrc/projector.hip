@@ -31,29 +31,16 @@ __global__ __launch_bounds__(256, 2) void nsgp_projector_kernel(const float* __r
     const int wm = wave >> 1, wn = wave & 1;
     f32x16 acc[2][2];
     zero_acc(acc);
-    float ra[4][4], rb[4][4];
+    float ra[2][4][4], rb[2][4][4];
     const int kbeg = first_col & ~(BK - 1);
-    const int nk = (D - kbeg + BK - 1) / BK;
-
-    stage_rows<FAST>(V, D, D, D, m0, kbeg, ra);
-    stage_rows<FAST>(V, D, D, D, n0, kbeg, rb);
-    write_rows_klo(a_img(smem, 0), ra, kbeg, first_col);
-    write_rows_klo(b_img(smem, 0), rb, kbeg, first_col);
-    __syncthreads();
-    for (int t = 0; t < nk; ++t) {
-        const int cur = t & 1;
-        const int knext = kbeg + (t + 1) * BK;
-        if (t + 1 < nk) {
-            stage_rows<FAST>(V, D, D, D, m0, knext, ra);
-            stage_rows<FAST>(V, D, D, D, n0, knext, rb);
-        }
-        mfma_kstep<true>(a_img(smem, cur), b_img(smem, cur), acc, wm, wn);
-        if (t + 1 < nk) {
-            write_rows_klo(a_img(smem, cur ^ 1), ra, knext, first_col);
-            write_rows_klo(b_img(smem, cur ^ 1), rb, knext, first_col);
-        }
-        __syncthreads();
-    }
+    mfma_pipeline<true>(
+        (D - kbeg + BK - 1) / BK, smem, acc,
+        [&](int t, auto s) {
+            stage_rows<FAST>(V, D, D, D, m0, kbeg + t * BK, ra[decltype(s)::value]);
+            stage_rows<FAST>(V, D, D, D, n0, kbeg + t * BK, rb[decltype(s)::value]);
+        },
+        [&](float* img, int t, auto s) { write_rows_klo(img, ra[decltype(s)::value], kbeg + t * BK, first_col); },
+        [&](float* img, int t, auto s) { write_rows_klo(img, rb[decltype(s)::value], kbeg + t * BK, first_col); });
 #pragma unroll
     for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
@@ -63,8 +50,8 @@ __global__ __launch_bounds__(256, 2) void nsgp_projector_kernel(const float* __r
             for (int r = 0; r < 16; ++r) {
                 const int row = m0 + wm * 64 + mi * 32 + acc_row(r, lane);
                 if (row < D && col < D) {
-                    P[(long)row * D + col] = acc[mi][ni][r];
-                    if (m0 != n0) P[(long)col * D + row] = acc[mi][ni][r];
+                    as_global(P)[(long)row * D + col] = acc[mi][ni][r];
+                    if (m0 != n0) as_global(P)[(long)col * D + row] = acc[mi][ni][r];
                 }
             }
         }

@@ -49,26 +49,15 @@ __global__ __launch_bounds__(256, 2) void repre_sim_mask_kernel(const float* __r
         da[j] = ra_ < N ? nrm[ra_] : 1.0f;
         db[j] = rb_ < N ? nrm[rb_] : 1.0f;
     }
-    float ra[4][4], rb[4][4];
-    const int nk = (D + BK - 1) / BK;
-    stage_rows<FAST>(F, D, N, D, m0, 0, ra);
-    stage_rows<FAST>(F, D, N, D, n0, 0, rb);
-    write_rows_div(a_img(smem, 0), ra, da);
-    write_rows_div(b_img(smem, 0), rb, db);
-    __syncthreads();
-    for (int k = 0; k < nk; ++k) {
-        const int cur = k & 1;
-        if (k + 1 < nk) {
-            stage_rows<FAST>(F, D, N, D, m0, (k + 1) * BK, ra);
-            stage_rows<FAST>(F, D, N, D, n0, (k + 1) * BK, rb);
-        }
-        mfma_kstep<true>(a_img(smem, cur), b_img(smem, cur), acc, wm, wn);
-        if (k + 1 < nk) {
-            write_rows_div(a_img(smem, cur ^ 1), ra, da);
-            write_rows_div(b_img(smem, cur ^ 1), rb, db);
-        }
-        __syncthreads();
-    }
+    float ra[2][4][4], rb[2][4][4];
+    mfma_pipeline<true>(
+        (D + BK - 1) / BK, smem, acc,
+        [&](int k, auto s) {
+            stage_rows<FAST>(F, D, N, D, m0, k * BK, ra[decltype(s)::value]);
+            stage_rows<FAST>(F, D, N, D, n0, k * BK, rb[decltype(s)::value]);
+        },
+        [&](float* img, int, auto s) { write_rows_div(img, ra[decltype(s)::value], da); },
+        [&](float* img, int, auto s) { write_rows_div(img, rb[decltype(s)::value], db); });
     // ---- epilogue: accumulators -> bit matrix ---------------------------------------------
     const int h = lane >> 5, c = lane & 31;
 #pragma unroll

@@ -181,6 +181,22 @@ class NSCLOptimizerBase(Optimizer):
             tot = [tot[0] + f.value, tot[1] + b.value, tot[2] + t.value, tot[3] + n.value]
         return tuple(tot)
 
+    def profile_begin(self, max_steps=1024):
+        """Record HIP events around both launches of the next ``max_steps`` steps (measurement)."""
+        lib = _lib.load_library()
+        for plan in self._plans:
+            _lib.check(lib.nsgp_plan_profile_begin(plan["handle"], max_steps), "nsgp_plan_profile_begin")
+
+    def profile_end(self):
+        """(n_steps, avg elementwise-launch ms, avg projection-GEMM ms), summed over plans."""
+        lib = _lib.load_library()
+        n_, u_, g_ = 0, 0.0, 0.0
+        for plan in self._plans:
+            n, u, g = C.c_int(), C.c_float(), C.c_float()
+            _lib.check(lib.nsgp_plan_profile_end(plan["handle"], C.byref(n), C.byref(u), C.byref(g)), "nsgp_plan_profile_end")
+            n_, u_, g_ = max(n_, n.value), u_ + u.value, g_ + g.value
+        return n_, u_, g_
+
     @torch.no_grad()
     def step(self, closure=None):
         """One optimization step (SGD_NSCL.py:59-96 semantics, every listed (name, p) pair)."""

@@ -1,0 +1,114 @@
+"""Regional Prototype Replay RoI heads -- interface mirror of
+mmdet/models/roi_heads/standard_roi_replay_head.py (``StandardRoIReplayHead`` :30,
+``StandardMultiPrototypeReplayHead`` :375-501).
+
+``PrototypeReplay`` carries the fork's own logic (bank construction at start of task t, the
+per-step replay loss) against any object that has a ``bbox_head``; when mmdet is importable the
+registered head classes also inherit ``StandardRoIHead`` so the reference configs build them
+unchanged, and without mmdet they are plain ``nn.Module`` containers with the same constructor
+keywords.
+"""
+import os.path as osp
+from typing import Optional, Sequence
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from ..registry import MODELS, register
+from .prototype_bank import build_prototype_bank
+
+try:  # pragma: no cover - mmdet is absent in this image
+    from mmdet.models.roi_heads.standard_roi_head import StandardRoIHead as _Base
+    _HAVE_MMDET = True
+except Exception:
+    _Base = nn.Module
+    _HAVE_MMDET = False
+
+
+def get_work_dir(previous_path: str) -> str:
+    """standard_roi_replay_head.py:363-370: the current work dir is the previous one with its
+    trailing ``_N`` bumped; paths containing "coco" map to "./"."""
+    if "coco" in previous_path:
+        return "./"
+    parts = previous_path.split("_")
+    parts[-1] = str(int(parts[-1]) + 1)
+    return "_".join(parts)
+
+
+class PrototypeReplay:
+    """Bank construction + replay loss, independent of the detector framework."""
+
+    def init_prototype_replay(self, previous_path: Optional[str], task_id: int, task_split: Sequence[int],
+                              max_prototype: int = 10, device=None):
+        self.replay = False
+        self.task_split = list(task_split)
+        self.task_id = task_id
+        self.max_proto = max_prototype
+        if previous_path is None or not osp.exists(previous_path):
+            return
+        assert task_id != 1                                                       # head:400
+        if device is None:
+            device = torch.device("cuda", torch.cuda.current_device())
+        self.replay = True
+        with torch.no_grad():
+            rois = torch.load(osp.join(previous_path, "rois_etc.pth"), map_location=device, weights_only=True)
+            (feats, self.cls_targets, self.cls_weights, self.bbox_targets, self.bbox_weights, self.roiss) = rois
+            mask_file = osp.join(previous_path, "mask.pth")
+            saved = torch.load(mask_file, map_location="cpu", weights_only=True) if osp.exists(mask_file) else []
+            feats = feats.reshape(feats.shape[0], -1).float().contiguous()
+            bank, labels, masks, _ = build_prototype_bank(feats, self.cls_targets, self.task_split, task_id,
+                                                          max_prototype, saved=saved)
+            self.bbox_featss = bank                                               # [K x 12544]
+            self.tmp_label = labels                                               # [K] int64
+            # the (possibly extended) mask list goes to the CURRENT work dir (head:451-452)
+            merged = list(saved)
+            for c, ml in zip(range(self.task_split[0], self.task_split[task_id - 1]), masks):
+                if c < len(merged):
+                    merged[c] = ml
+                else:
+                    merged.append(ml)
+            torch.save(merged, osp.join(get_work_dir(previous_path), "mask.pth"))
+
+    def replay_loss(self, bbox_feats, sampling_results=None, rois=None) -> dict:
+        """head:468-501: the bank through the bbox head; keep the columns of the classes seen so
+        far + background; ``CE(softmax(.), labels)`` (the double softmax is the reference's)."""
+        if getattr(self, "with_shared_head", False):
+            bbox_feats = self.shared_head(bbox_feats)
+        cls_score, bbox_pred = self.bbox_head(bbox_feats)
+        results = dict(cls_score=cls_score, bbox_pred=bbox_pred, bbox_feats=bbox_feats)
+        pre_idx = self.task_split[self.task_id]
+        kept = torch.cat([cls_score[:, :pre_idx], cls_score[:, -1:]], dim=-1)
+        loss = F.cross_entropy(kept.softmax(dim=-1), self.tmp_label.to(kept.device))
+        results.update(replay_loss=dict(replay_loss_cls=loss))
+        return results
+
+    def add_replay_loss(self, losses: dict) -> dict:
+        """The tail of ``loss`` (head:454-466): stock RoI losses + ``replay_loss_cls``."""
+        if self.replay:
+            losses.update(self.replay_loss(self.bbox_featss)["replay_loss"])
+        return losses
+
+
+@register(MODELS)
+class StandardMultiPrototypeReplayHead(PrototypeReplay, _Base):
+    """Same keywords as the reference (head:377-390)."""
+
+    def __init__(self, bbox_roi_extractor=None, bbox_head=None, mask_roi_extractor=None, mask_head=None,
+                 shared_head=None, train_cfg=None, test_cfg=None, init_cfg=None, previous_path=None, task_id=1,
+                 task_split=(0, 10, 20), max_prototype=10, work_dir=None):
+        if _HAVE_MMDET:  # pragma: no cover
+            super().__init__(bbox_roi_extractor, bbox_head, mask_roi_extractor, mask_head, shared_head, train_cfg,
+                             test_cfg, init_cfg)
+        else:
+            nn.Module.__init__(self)
+            if isinstance(bbox_head, dict):
+                bbox_head = MODELS.build(bbox_head)
+            self.bbox_head = bbox_head
+            self.train_cfg, self.test_cfg = train_cfg, test_cfg
+        self.init_prototype_replay(previous_path, task_id, task_split, max_prototype)
+
+    def loss(self, x, rpn_results_list, batch_data_samples) -> dict:
+        if not _HAVE_MMDET:
+            raise RuntimeError("the stock RoI loss needs mmdet; the replay part is `add_replay_loss`")
+        return self.add_replay_loss(_Base.loss(self, x, rpn_results_list, batch_data_samples))  # pragma: no cover

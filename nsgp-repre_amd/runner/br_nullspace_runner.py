@@ -1,0 +1,143 @@
+"""``BRNullSpaceRunner`` -- task orchestration around the hot path
+(mmdet/engine/runner/nsrunner_roi_replay.py:111-1031).
+
+Two faces of one class name:
+
+* with MMEngine installed the registered ``BRNullSpaceRunner`` subclasses ``mmengine.runner.Runner``
+  and reads the same top-level config keys as the reference (``task_id, train_task_split, offset,
+  ignore_keys, previous_dir, ckpt_keywords, reserve_per_class, is_trained``; runner:288-362,
+  416-418) so ``tools/train.py``'s ``RUNNERS.build(cfg)`` picks it up unchanged;
+* without MMEngine (this image) it is a small stand-alone driver over plain torch objects with the
+  same method names, which is what the tests exercise.
+
+Both delegate every NSGP/RePRE step to ``runner/nullspace.py``.  Out of scope here:
+the EWC regulariser and the teacher pseudo-labelling.
+"""
+import os.path as osp
+from typing import Callable, Iterable, Optional, Sequence
+
+import torch
+
+from ..registry import HAVE_MMENGINE, RUNNERS, register
+from . import nullspace as NS
+
+
+class NullSpaceTaskMixin:
+    """The fork's additions to the runner, framework-agnostic."""
+
+    def init_task_state(self, work_dir: str, task_id: int = 1, train_task_split: Optional[Sequence[int]] = None,
+                        previous_dir: Optional[str] = None, ckpt_keywords: str = "best",
+                        ignore_keys: Optional[Sequence[str]] = None, offset: float = 0.0, reserve_per_class: int = 0,
+                        is_trained: bool = False, fea_in_load_path: Optional[str] = None):
+        self.task_id = task_id if task_id is not None else 1
+        self.task_split = train_task_split
+        self.previous_dir = previous_dir if self.task_id != 1 else None
+        self.ckpt_keywords = ckpt_keywords
+        if self.previous_dir is None or not osp.exists(self.previous_dir):
+            assert self.task_id == 1, "Error, previous task dir should be fed into the runner."      # runner:292
+        self.fea_in_save_path = osp.join(work_dir, "covariance.pth")                                  # runner:346
+        self.fea_in_load_path = fea_in_load_path or (osp.join(self.previous_dir, "covariance.pth")
+                                                     if self.previous_dir is not None else None)
+        self.ignore_keys = NS.full_ignore_keys(ignore_keys)                                           # runner:355
+        self.offset = offset or 0.0
+        self.reserve_per_class = reserve_per_class or 0
+        self.is_trained = bool(is_trained)
+        self._task_work_dir = work_dir
+
+    # -- start of task t >= 2 ------------------------------------------------------------------
+    def wire_param_names(self, optimizer, model):
+        NS.wire_param_names(optimizer, model)
+
+    def update_optim_transforms(self, optimizer, model):
+        """runner:635-662 (the duplicate ``update_model_transforms`` :665-692 is folded in)."""
+        dev = next(NS.unwrap(model).parameters()).device
+        return NS.update_optim_transforms(optimizer, self.fea_in_load_path, self.ignore_keys, self.offset, dev)
+
+    # -- end of task t --------------------------------------------------------------------------
+    def cal_fea_in(self, model, batches: Iterable, forward: Optional[Callable] = None):
+        return NS.cal_fea_in(model, batches, self.ignore_keys, self.fea_in_save_path,
+                             self.fea_in_load_path if self.task_id != 1 else None, self.task_id, forward)
+
+    def cal_rois(self, model, batches: Iterable, forward: Optional[Callable] = None, num_classes: int = 20):
+        prev = osp.join(self.previous_dir, "rois_etc.pth") if (self.task_id != 1 and self.previous_dir) else None
+        return NS.cal_rois(model, batches, osp.join(self._task_work_dir, "rois_etc.pth"), prev, self.task_id,
+                           self.reserve_per_class, num_classes, forward)
+
+
+if HAVE_MMENGINE:  # pragma: no cover - exercised only where mmengine is installed
+    from mmengine.runner import Runner as _Runner
+
+    @register(RUNNERS)
+    class BRNullSpaceRunner(NullSpaceTaskMixin, _Runner):
+        @classmethod
+        def from_cfg(cls, cfg):
+            runner = super().from_cfg(cfg)
+            runner.init_task_state(runner.work_dir, cfg.get("task_id"), cfg.get("train_task_split"),
+                                   cfg.get("previous_dir"), cfg.get("ckpt_keywords", "best"), cfg.get("ignore_keys"),
+                                   cfg.get("offset"), cfg.get("reserve_per_class"), cfg.get("is_trained"),
+                                   cfg.get("fea_in_load_path"))
+            return runner
+
+        def train(self):
+            model = NS.unwrap(self.model)
+            self._train_loop = self.build_train_loop(self._train_loop)
+            self.optim_wrapper = self.build_optim_wrapper(self.optim_wrapper)
+            self.wire_param_names(self.optim_wrapper.optimizer, model)                               # runner:473-484
+            self.scale_lr(self.optim_wrapper, self.auto_scale_lr)
+            if self.param_schedulers is not None:
+                self.param_schedulers = self.build_param_scheduler(self.param_schedulers)
+            if self._val_loop is not None:
+                self._val_loop = self.build_val_loop(self._val_loop)
+            self.call_hook("before_run")
+            self._init_model_weights()
+            self.load_or_resume()
+            if self.task_id != 1 and not self.is_trained:
+                assert self._resume is False                                                          # runner:551
+                NullSpaceTaskMixin.update_optim_transforms(self, self.optim_wrapper.optimizer, model)
+            self.optim_wrapper.initialize_count_status(self.model, self._train_loop.iter, self._train_loop.max_iters)
+            if not self.is_trained:
+                self.train_loop.run()
+            self.call_hook("after_run")
+            self._has_loaded = False
+
+            def fwd_ns(net, data_batch):
+                data = net.data_preprocessor(data_batch, True)
+                net(data["inputs"], data["data_samples"], mode="nullspace")
+
+            def fwd_roi(net, data_batch):
+                data = net.data_preprocessor(data_batch, True)
+                return net(data["inputs"], data["data_samples"], mode="roi_replay")
+            self.cal_fea_in(self.model, self.train_dataloader, fwd_ns)
+            self.cal_rois(self.model, self.train_dataloader, fwd_roi)
+            return self.model
+else:
+
+    @register(RUNNERS)
+    class BRNullSpaceRunner(NullSpaceTaskMixin):
+        """Stand-alone driver: ``model`` + NSGP ``optimizer`` + an iterable of batches.
+
+        ``train(step_fn, batches)`` wires the names, builds the projectors for task >= 2, runs
+        ``step_fn(model, batch) -> loss`` / ``backward`` / ``optimizer.step`` per batch, then does the
+        end-of-task covariance pass and (if a RoI forward is given) the RoI dump."""
+
+        def __init__(self, model, optimizer, work_dir: str, **task_kwargs):
+            self.model, self.optimizer, self.work_dir = model, optimizer, work_dir
+            self.init_task_state(work_dir, **task_kwargs)
+
+        def train(self, step_fn: Callable, batches: Iterable, cov_forward: Optional[Callable] = None,
+                  cov_batches: Optional[Iterable] = None, roi_forward: Optional[Callable] = None):
+            self.wire_param_names(self.optimizer, self.model)
+            if self.task_id != 1 and not self.is_trained:
+                self.update_optim_transforms(self.optimizer, self.model)
+            if not self.is_trained:
+                NS.unwrap(self.model).train()
+                for batch in batches:
+                    loss = step_fn(self.model, batch)
+                    self.optimizer.zero_grad()
+                    loss.backward()
+                    self.optimizer.step()
+            cov = self.cal_fea_in(self.model, cov_batches if cov_batches is not None else batches, cov_forward)
+            rois = None
+            if roi_forward is not None:
+                rois = self.cal_rois(self.model, cov_batches if cov_batches is not None else batches, roi_forward)
+            return cov, rois

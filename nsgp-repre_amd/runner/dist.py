@@ -1,0 +1,80 @@
+"""The three explicit exchange steps of the hot path, on torch.distributed
+(backend 'nccl' = RCCL over xGMI on ROCm; 'gloo' in the CPU tests).
+
+C1  ``all_reduce_dict``             -- nsrunner_roi_replay.py:746-749 via mmengine.dist: SUM the per-rank
+     covariance dict.  One flat buffer, ONE all-reduce (0.589 GB fp32 for R-50-FPN), split back.
+C2  ``all_gather_different_shape``  -- nsrunner_roi_replay.py:73-105.  The reference emulates a ragged
+     gather with 2*W zero-padded all-reduces per tensor (O(W*N) traffic per rank pair).  Here: one tiny
+     all-gather of the row counts + ONE all-gather of the padded payload; same returned list.
+C3  the DDP gradient all-reduce stays PyTorch's (RCCL) and is not re-implemented.
+Without an initialised process group (single GPU) every function is the identity.
+"""
+from typing import Dict, List
+
+import torch
+import torch.distributed as dist
+
+
+def _active():
+    return dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+
+
+def get_rank():
+    return dist.get_rank() if (dist.is_available() and dist.is_initialized()) else 0
+
+
+def get_world_size():
+    return dist.get_world_size() if (dist.is_available() and dist.is_initialized()) else 1
+
+
+def barrier():
+    if _active():
+        dist.barrier()
+
+
+def all_reduce_dict(data: Dict[str, torch.Tensor], op: str = "sum") -> None:
+    """In-place SUM (or mean) of every tensor of ``data`` over ranks; keys are processed in sorted
+    order on every rank (mmengine does the same) so the flat layouts agree."""
+    if not _active() or len(data) == 0:
+        return
+    keys = sorted(data.keys())
+    flat = torch.cat([data[k].reshape(-1) for k in keys])
+    dist.all_reduce(flat, op=dist.ReduceOp.SUM)
+    if op == "mean":
+        flat /= dist.get_world_size()
+    off = 0
+    for k in keys:
+        n = data[k].numel()
+        data[k].copy_(flat[off:off + n].view_as(data[k]))
+        off += n
+
+
+def all_gather_different_shape(t: torch.Tensor) -> List[torch.Tensor]:
+    """Every rank receives ``[t_rank0, t_rank1, ...]`` where the first dimension may differ."""
+    if not _active():
+        return [t]
+    world = dist.get_world_size()
+    n_local = torch.tensor([t.shape[0]], dtype=torch.int64, device=t.device)
+    counts = [torch.zeros_like(n_local) for _ in range(world)]
+    dist.all_gather(counts, n_local)
+    counts = [int(c.item()) for c in counts]
+    n_max = max(counts)
+    padded = torch.zeros((n_max,) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
+    padded[:t.shape[0]] = t
+    out = [torch.empty_like(padded) for _ in range(world)]
+    dist.all_gather(out, padded)
+    return [o[:c] for o, c in zip(out, counts)]
+
+
+def shard_by_cost(costs: List[float], world: int) -> List[int]:
+    """Greedy longest-first assignment of independent units (layers, classes) to ranks; returns the
+    owner rank of each unit.  Used to spread the once-per-task eigendecompositions / prototype
+    builds over ranks before an all-gather of the results."""
+    order = sorted(range(len(costs)), key=lambda i: -costs[i])
+    load = [0.0] * world
+    owner = [0] * len(costs)
+    for i in order:
+        r = min(range(world), key=lambda x: load[x])
+        owner[i] = r
+        load[r] += costs[i]
+    return owner

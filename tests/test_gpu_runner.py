@@ -1,0 +1,165 @@
+"""GPU tests of the runner / head layer: covariance hooks, file hand-off between tasks, the
+stand-alone BRNullSpaceRunner, and the defining property of NSGP (updates do not move the old
+task's features)."""
+import os
+import tempfile
+
+import numpy as np
+import pytest
+import torch
+import torch.nn as nn
+
+import inputs as I
+import nsgp_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def N():
+    import nsgp_repre_amd
+    assert torch.cuda.is_available()
+    return nsgp_repre_amd
+
+
+@pytest.fixture(scope="module")
+def dev():
+    return torch.device("cuda:0")
+
+
+def _rel(a, b):
+    a, b = a.detach().cpu().double(), b.detach().cpu().double()
+    return ((a - b).abs().max() / b.abs().max().clamp_min(1e-30)).item()
+
+
+class Net(nn.Module):
+    def __init__(self):
+        super().__init__()
+        self.backbone = nn.Sequential()
+        self.backbone.add_module("conv1", nn.Conv2d(3, 16, 3, padding=1))
+        self.backbone.add_module("bn1", nn.BatchNorm2d(16))
+        self.backbone.add_module("relu", nn.ReLU())
+        self.backbone.add_module("conv2", nn.Conv2d(16, 16, 3, stride=2, padding=1))
+        self.neck = nn.Conv2d(16, 8, 1)
+        self.rpn_head = nn.Conv2d(8, 4, 3, padding=1)
+        self.fc = nn.Linear(8, 5)
+
+    def forward(self, x):
+        f = self.neck(torch.relu(self.backbone(x)))
+        return self.rpn_head(f).mean() + self.fc(f.mean(dim=(2, 3))).mean()
+
+
+def _oracle_covariances(net_cpu, batches, ignore):
+    """The reference's route on the CPU: hooks + unfold + mm (restated in the oracle)."""
+    fea = {}
+    acts = {}
+    hs = []
+    for n, m in net_cpu.named_modules():
+        if isinstance(m, (nn.Conv2d, nn.Linear)) and not any(__import__("re").match(k, n) for k in ignore):
+            hs.append(m.register_forward_hook(lambda mod, i, o, n=n: acts.__setitem__(n, (mod, i[0].detach()))))
+    net_cpu.eval()
+    with torch.no_grad():
+        for x in batches:
+            acts.clear()
+            net_cpu(x)
+            for n, (mod, a) in acts.items():
+                c = O.cov_conv2d(a, mod.kernel_size, mod.stride, mod.padding) if isinstance(mod, nn.Conv2d) else O.cov_linear(a)
+                O.update_cov(fea, n + ".weight", c)
+    for h in hs:
+        h.remove()
+    return fea
+
+
+def test_cal_fea_in_matches_oracle_and_accumulates_previous_task(N, dev):
+    torch.manual_seed(0)
+    net_cpu = Net()
+    net = Net().to(dev)
+    net.load_state_dict(net_cpu.state_dict())
+    batches = [torch.randn(2, 3, 20, 28) for _ in range(3)]
+    ignore = N.runner.full_ignore_keys(["rpn", "roi_head"])
+    ref = _oracle_covariances(net_cpu, batches, ignore)
+    with tempfile.TemporaryDirectory() as td:
+        p1 = os.path.join(td, "covariance_t1.pth")
+        cov = N.runner.cal_fea_in(net, [b.to(dev) for b in batches], ignore, save_path=p1, task_id=1)
+        assert sorted(cov) == sorted(ref) == ["backbone.conv1.weight", "backbone.conv2.weight", "fc.weight", "neck.weight"]
+        for k in ref:
+            assert _rel(cov[k], ref[k]) <= 1e-5, k
+        loaded = torch.load(p1, weights_only=True)          # the on-disk contract: dict[str -> [D x D]]
+        assert sorted(loaded) == sorted(ref)
+        # task 2: the new covariance is ADDED to the previous file's (runner:751-754)
+        cov2 = N.runner.cal_fea_in(net, [b.to(dev) for b in batches], ignore, previous_path=p1, task_id=2)
+        for k in ref:
+            assert _rel(cov2[k], 2 * ref[k]) <= 1e-5, k
+    assert not any(len(m._forward_hooks) for m in net.modules())   # hooks removed
+
+
+def test_prototype_replay_head_from_files(N, dev, golden_dir):
+    """rois_etc.pth -> bank + mask.pth in the next work dir; then mask.pth replayed gives the same bank."""
+    g = np.load(os.path.join(golden_dir, "g4_prototypes.npz"))
+    feats, cls = I.g4_rois()
+    n = feats.shape[0]
+    rois = [torch.from_numpy(feats), torch.from_numpy(cls), torch.ones(n), torch.zeros(n, 4), torch.zeros(n, 4), torch.zeros(n, 5)]
+    with tempfile.TemporaryDirectory() as td:
+        prev, cur, nxt = (os.path.join(td, f"x_15_5_{i}") for i in (1, 2, 3))
+        for d in (prev, cur, nxt):
+            os.makedirs(d)
+        torch.save(rois, os.path.join(prev, "rois_etc.pth"))
+        bbox_head = N.roi_heads.Shared2FCBBoxHeadTask(in_channels=256, fc_out_channels=64, roi_feat_size=7, num_classes=5,
+                                                      task_split=I.G4_TASK_SPLIT, task_id=2).to(dev)
+        head = N.roi_heads.StandardMultiPrototypeReplayHead(bbox_head=bbox_head, previous_path=prev, task_id=2,
+                                                            task_split=I.G4_TASK_SPLIT, max_prototype=I.G4_MAX_PROTO)
+        assert head.replay
+        np.testing.assert_array_equal(head.tmp_label.cpu().numpy(), g["labels"])
+        assert _rel(head.bbox_featss, torch.from_numpy(g["bank"])) <= 1e-5
+        masks = torch.load(os.path.join(cur, "mask.pth"), weights_only=True)
+        for c in range(3):
+            assert len(masks[c]) == int(g[f"nmask_{c}"])
+            for j, m in enumerate(masks[c]):
+                np.testing.assert_array_equal(m.numpy(), g[f"mask_{c}_{j}"])
+        losses = head.add_replay_loss({})
+        assert torch.isfinite(losses["replay_loss_cls"])
+        losses["replay_loss_cls"].backward()
+        assert bbox_head.shared_fcs[0].weight.grad.abs().sum() > 0
+        # a later run finds mask.pth next to rois_etc.pth and replays it (head:407-408, 425-433)
+        torch.save(rois, os.path.join(cur, "rois_etc.pth"))
+        head2 = N.roi_heads.StandardMultiPrototypeReplayHead(bbox_head=bbox_head, previous_path=cur, task_id=2,
+                                                             task_split=I.G4_TASK_SPLIT, max_prototype=I.G4_MAX_PROTO)
+        assert _rel(head2.bbox_featss, torch.from_numpy(g["bank"])) <= 1e-5
+    no_replay = N.roi_heads.StandardMultiPrototypeReplayHead(bbox_head=bbox_head, previous_path=None)
+    assert not no_replay.replay and no_replay.add_replay_loss({}) == {}
+
+
+def test_two_task_run_keeps_old_features_fixed(N, dev):
+    """End-to-end on a tiny conv net: task 1 (plain SGD) -> covariance.pth -> task 2 with NSGP.
+    Property: for a projected conv, the weight change dW applied to any OLD-task input patch x
+    (a row of X) stays tiny relative to the un-projected change: ||X dW^T|| << ||X dW_plain^T||."""
+    torch.manual_seed(1)
+    data1 = [torch.randn(2, 3, 16, 16, device=dev) * torch.tensor([1.0, 0.1, 0.01], device=dev).view(1, 3, 1, 1) for _ in range(4)]
+    data2 = [torch.randn(2, 3, 16, 16, device=dev) for _ in range(4)]
+    with tempfile.TemporaryDirectory() as td:
+        w1, w2 = os.path.join(td, "run_1"), os.path.join(td, "run_2")
+        os.makedirs(w1); os.makedirs(w2)
+        net = Net().to(dev)
+        opt = N.SGDNSCL(net.parameters(), lr=0.05, momentum=0.9, svd=True)
+        r1 = N.runner.BRNullSpaceRunner(net, opt, w1, task_id=1, ignore_keys=["rpn", "roi_head"])
+        cov, _ = r1.train(lambda m, b: m(b), data1)
+        assert os.path.exists(os.path.join(w1, "covariance.pth")) and len(opt.transforms) == 0
+        before = {n: p.detach().clone() for n, p in net.named_parameters()}
+        opt2 = N.SGDNSCL(net.parameters(), lr=0.05, momentum=0.9, svd=True)
+        r2 = N.runner.BRNullSpaceRunner(net, opt2, w2, task_id=2, previous_dir=w1, ignore_keys=["rpn", "roi_head"])
+        r2.train(lambda m, b: m(b), data2)
+        assert sorted(opt2.transforms.keys()) == ["backbone.conv1.weight", "backbone.conv2.weight", "fc.weight", "neck.weight"]
+        assert "rpn_head.weight" not in opt2.transforms
+        name = "backbone.conv1.weight"
+        P = opt2.transforms[name]
+        dW = (dict(net.named_parameters())[name].detach() - before[name]).view(16, -1)
+        # dW lies in the row space of P (dW = U P): re-projecting changes nothing
+        Pn = P * P.norm()                                   # undo the backbone 1/||P||_F scale -> a projector
+        assert _rel(dW @ Pn, dW) <= 1e-3
+        # and it annihilates the dominant old-task input directions
+        lam, Q = torch.linalg.eigh(cov[name])
+        top = Q[:, -3:]                                      # top-3 eigen-directions of the old covariance
+        assert (dW @ top).norm() <= 1e-3 * dW.norm()
+        assert dW.norm() > 0
+        # task 2's own covariance file = task 1's + the new pass (checked in the cal_fea_in test)
+        assert os.path.exists(os.path.join(w2, "covariance.pth"))

@@ -1,0 +1,207 @@
+"""CPU tests of the runner / head host logic and of the N>1 exchange steps (gloo, world_size 2)."""
+import os
+import tempfile
+
+import numpy as np
+import pytest
+import torch
+import torch.nn as nn
+
+import inputs as I
+import nsgp_oracle as O
+
+
+@pytest.fixture(scope="module")
+def N():
+    import nsgp_repre_amd
+    return nsgp_repre_amd
+
+
+class TinyNet(nn.Module):
+    def __init__(self):
+        super().__init__()
+        self.backbone = nn.Sequential()
+        self.backbone.add_module("conv1", nn.Conv2d(3, 8, 3, padding=1))
+        self.backbone.add_module("bn1", nn.BatchNorm2d(8))
+        self.backbone.add_module("conv2", nn.Conv2d(8, 8, 3, stride=2, padding=1))
+        self.neck = nn.Conv2d(8, 4, 1)
+        self.rpn_head = nn.Conv2d(4, 4, 3, padding=1)
+        self.roi_head = nn.Module()
+        self.roi_head.bbox_head = nn.Module()
+        self.roi_head.bbox_head.fc_cls = nn.Linear(4, 3)
+
+    def forward(self, x):
+        return self.rpn_head(self.neck(self.backbone(x)))
+
+
+def test_registry_has_every_reference_name(N):
+    r = N.registry
+    assert r.RUNNERS.get("BRNullSpaceRunner") is N.runner.BRNullSpaceRunner
+    for name in ("FasterRCNNRoIReplay", "StandardMultiPrototypeReplayHead", "Shared2FCBBoxHeadTask", "ConvFCBBoxHeadTask"):
+        assert r.MODELS.get(name) is not None, name
+
+
+def test_wire_param_names_follows_named_parameters(N):
+    net = TinyNet()
+    net.backbone.conv1.weight.requires_grad_(False)          # frozen stage drops out of the optimizer
+    bn = [p for n, p in net.named_parameters() if "bn" in n]
+    rest = [p for n, p in net.named_parameters() if "bn" not in n]
+    opt = N.SGDNSCL([dict(params=rest), dict(params=bn, weight_decay=0.0)], lr=0.1)
+    N.runner.wire_param_names(opt, net)
+    names0, names1 = opt.param_groups[0]["names"], opt.param_groups[1]["names"]
+    assert "backbone.conv1.weight" not in names0 and "backbone.conv1.bias" in names0
+    assert names1 == ["backbone.bn1.weight", "backbone.bn1.bias"]
+    expected = [n for n, p in net.named_parameters() if p.requires_grad and "bn" not in n]
+    assert names0 == expected
+    for g in opt.param_groups:
+        assert len(g["names"]) == len(g["params"])
+        for n, p in zip(g["names"], g["params"]):
+            assert dict(net.named_parameters())[n] is p
+
+
+def test_ignore_keys_are_anchored_regexes(N):
+    keys = N.runner.full_ignore_keys(["rpn", "roi_head"])
+    assert keys[-3:] == ["roi_head.bbox_head.fc_cls", "roi_head.bbox_head.fc_reg", "teacher"]
+    assert N.runner.should_ignore("rpn_head.rpn_conv.weight", keys)
+    assert N.runner.should_ignore("roi_head.bbox_head.shared_fcs.0.weight", keys)
+    assert N.runner.should_ignore("teacher_model.backbone.conv1.weight", keys)
+    assert not N.runner.should_ignore("backbone.layer1.0.conv1.weight", keys)
+    assert not N.runner.should_ignore("neck.rpn_like.weight", keys)      # re.match anchors at the start
+    net = TinyNet()
+    col = N.runner.CovarianceCollector(net, keys)
+    hooked = [n for n, _ in col.hooked_modules()]
+    assert hooked == ["backbone.conv1", "backbone.bn1", "backbone.conv2", "neck"]
+    assert O.filter_ignore({"rpn_head.x.weight": 1, "neck.weight": 2}, keys) == {"neck.weight": 2}
+
+
+def test_get_work_dir_and_find_checkpoint(N):
+    from nsgp_repre_amd.roi_heads import get_work_dir
+    assert get_work_dir("./work_dirs/ns3/cl_faster_rcnn_15_5_1") == "./work_dirs/ns3/cl_faster_rcnn_15_5_2"
+    assert get_work_dir("./work_dirs/cl_coco/x_40_40_1") == "./"
+    with tempfile.TemporaryDirectory() as td:
+        open(os.path.join(td, "best_pascal_voc_mAP_epoch_3.pth"), "w").close()
+        assert N.runner.find_checkpoint(td, "best").endswith("best_pascal_voc_mAP_epoch_3.pth")
+        with pytest.raises(FileNotFoundError):
+            N.runner.find_checkpoint(td, "nothing")
+
+
+def test_task_head_forward_and_replay_loss_vs_reference_golden(N, golden_dir):
+    """Shared2FCBBoxHeadTask + PrototypeReplay.replay_loss are pure torch: check them on the CPU
+    against the reference's own outputs (G5)."""
+    g = np.load(os.path.join(golden_dir, "g5_replay_loss.npz"))
+    w = I.g5_weights()
+    head = N.roi_heads.Shared2FCBBoxHeadTask(in_channels=4, fc_out_channels=I.G5_FC, roi_feat_size=7, num_classes=7,
+                                             task_split=I.G5_TASK_SPLIT, task_id=I.G5_TASK_ID)
+    with torch.no_grad():
+        for m, (W, b) in zip(head.shared_fcs, w["shared"]):
+            m.weight.copy_(torch.from_numpy(W)); m.bias.copy_(torch.from_numpy(b))
+        for m, (W, b) in zip(head.fc_cls, w["cls"]):
+            m.weight.copy_(torch.from_numpy(W)); m.bias.copy_(torch.from_numpy(b))
+        for m, (W, b) in zip(head.fc_reg, w["reg"]):
+            m.weight.copy_(torch.from_numpy(W)); m.bias.copy_(torch.from_numpy(b))
+    # the future task's heads are frozen, background stays trainable
+    assert [m.weight.requires_grad for m in head.fc_cls] == [True, True, False, True]
+    assert [m.weight.requires_grad for m in head.fc_reg] == [True, True, False]
+    bank, labels = I.g5_bank()
+
+    class Holder(N.roi_heads.PrototypeReplay):
+        pass
+    h = Holder()
+    h.bbox_head, h.task_split, h.task_id = head, I.G5_TASK_SPLIT, I.G5_TASK_ID
+    h.tmp_label, h.replay = torch.from_numpy(labels), True
+    h.bbox_featss = torch.from_numpy(bank).reshape(-1, 4, 7, 7)
+    res = h.replay_loss(h.bbox_featss)
+    score = res["cls_score"].detach().numpy()
+    np.testing.assert_array_equal(np.isinf(score), np.isinf(g["cls_score"]))
+    fin = np.isfinite(g["cls_score"])
+    np.testing.assert_allclose(score[fin], g["cls_score"][fin], rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(res["bbox_pred"].detach().numpy(), g["bbox_pred"], rtol=1e-5, atol=1e-6)
+    loss = res["replay_loss"]["replay_loss_cls"]
+    np.testing.assert_allclose(loss.item(), g["loss"], rtol=1e-6)
+    loss.backward()
+    for i, m in enumerate(head.shared_fcs):
+        np.testing.assert_allclose(m.weight.grad.numpy(), g[f"gW_shared{i}"], rtol=1e-4, atol=1e-7)
+    losses = h.add_replay_loss(dict(loss_cls=torch.tensor(1.0)))
+    assert set(losses) == {"loss_cls", "replay_loss_cls"}
+
+
+def test_detector_mode_dispatch(N):
+    calls = []
+
+    class Det(N.detectors.RoIReplayModes):
+        def loss(self, a, b, use_teacher_student=True):
+            calls.append(("loss", use_teacher_student))
+        def predict(self, a, b):
+            calls.append(("predict",))
+        def _forward(self, a, b):
+            calls.append(("tensor",))
+        def get_bbox_stuff(self, a, b):
+            calls.append(("roi",))
+    d = Det()
+    for m in ("loss", "predict", "tensor", "nullspace", "roi_replay"):
+        d.forward(None, None, mode=m)
+    assert calls == [("loss", True), ("predict",), ("tensor",), ("loss", False), ("roi",)]
+    with pytest.raises(RuntimeError):
+        d.forward(None, None, mode="bogus")
+
+
+def test_shard_by_cost_balances(N):
+    owner = N.runner.dist.shard_by_cost([d ** 3 for _, _, d in O.resnet_fpn_projected_layers(50)], 8)
+    assert len(owner) == 50 and set(owner) == set(range(8))
+    load = [0.0] * 8
+    for o, (_, _, d) in zip(owner, O.resnet_fpn_projected_layers(50)):
+        load[o] += d ** 3
+    # three indivisible 4608^3 decompositions dominate: the optimum is one of them alone on a rank
+    assert max(load) == 4608.0 ** 3
+
+
+def _dist_worker(rank, world, port, q):
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import nsgp_repre_amd as N
+    D = N.runner.dist
+    g = torch.Generator().manual_seed(100 + rank)
+    local = {"b.weight": torch.randn(6, 6, generator=g), "a.weight": torch.randn(3, 3, generator=g)}
+    mine = {k: v.clone() for k, v in local.items()}
+    D.all_reduce_dict(mine)                                   # C1
+    t = torch.arange((rank + 2) * 3, dtype=torch.float32).reshape(rank + 2, 3) + 100 * rank
+    parts = D.all_gather_different_shape(t)                   # C2, ragged first dim
+    empty = D.all_gather_different_shape(torch.zeros(0, 5) if rank == 0 else torch.ones(2, 5))
+    q.put((rank, {k: v.numpy() for k, v in local.items()}, {k: v.numpy() for k, v in mine.items()},
+           [p.numpy() for p in parts], [e.shape for e in empty]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_exchange_steps_gloo_world2(N):
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29500 + os.getpid() % 2000
+    procs = [ctx.Process(target=_dist_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = sorted([q.get(timeout=120) for _ in range(2)], key=lambda x: x[0])
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    locals_ = [{k: torch.from_numpy(v) for k, v in g[1].items()} for g in got]
+    ref = O.all_reduce_dict_sum(locals_)
+    for rank, _, reduced, parts, eshapes in got:
+        for k in ref:
+            np.testing.assert_allclose(reduced[k], ref[k].numpy(), rtol=1e-6)
+        exp = O.all_gather_different_shape([torch.arange((r + 2) * 3, dtype=torch.float32).reshape(r + 2, 3) + 100 * r for r in range(2)])
+        assert len(parts) == 2
+        for a, b in zip(parts, exp):
+            np.testing.assert_array_equal(a, b.numpy())
+        assert [tuple(s) for s in eshapes] == [(0, 5), (2, 5)]
+
+
+def test_exchange_steps_are_identity_without_process_group(N):
+    D = N.runner.dist
+    d = {"x": torch.ones(2, 2)}
+    D.all_reduce_dict(d)
+    assert torch.equal(d["x"], torch.ones(2, 2))
+    t = torch.arange(6.0).reshape(3, 2)
+    assert len(D.all_gather_different_shape(t)) == 1 and D.get_world_size() == 1 and D.get_rank() == 0

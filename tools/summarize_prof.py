@@ -1,0 +1,62 @@
+"""Reduce rocprofv3 CSV output to small per-kernel summaries (run on the GPU box).
+
+usage: python tools/summarize_prof.py <prof_dir> <out_dir>
+Keeps: kernel_stats (top 25 rows), per-kernel average duration of our kernels from the kernel
+trace, and per-kernel mean of every PMC counter for kernels whose name contains nsgp_/repre_.
+"""
+import csv
+import glob
+import os
+import sys
+from collections import defaultdict
+
+src, dst = sys.argv[1], sys.argv[2]
+os.makedirs(dst, exist_ok=True)
+OURS = ("nsgp_", "repre_")
+
+
+def short(name):
+    for key in ("nsgp_project_kernel", "nsgp_update_kernel", "nsgp_project_single_kernel", "nsgp_projector_kernel",
+                "nsgp_cov_syrk_kernel", "nsgp_cov_reduce_kernel", "nsgp_batch_mean_pad_kernel", "repre_sim_mask_kernel",
+                "repre_row_norm_kernel", "repre_masked_sum_kernel"):
+        if key in name:
+            tail = name[name.find(key):]
+            return tail[:80]
+    return name[:80]
+
+
+for f in glob.glob(os.path.join(src, "**", "*kernel_stats.csv"), recursive=True):
+    rows = list(csv.reader(open(f)))
+    with open(os.path.join(dst, "kernel_stats_top.csv"), "w", newline="") as o:
+        w = csv.writer(o)
+        for r in rows[:26]:
+            w.writerow([c[:120] for c in r])
+
+for f in glob.glob(os.path.join(src, "**", "*kernel_trace.csv"), recursive=True):
+    dur = defaultdict(list)
+    rd = csv.DictReader(open(f))
+    for r in rd:
+        n = r.get("Kernel_Name", "")
+        if any(k in n for k in OURS):
+            dur[short(n)].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
+    with open(os.path.join(dst, "our_kernels_duration_us.csv"), "w", newline="") as o:
+        w = csv.writer(o)
+        w.writerow(["kernel", "calls", "avg_us", "min_us", "max_us"])
+        for k, v in sorted(dur.items()):
+            w.writerow([k, len(v), sum(v) / len(v), min(v), max(v)])
+
+agg = defaultdict(lambda: defaultdict(list))
+for f in glob.glob(os.path.join(src, "**", "*counter_collection.csv"), recursive=True):
+    rd = csv.DictReader(open(f))
+    for r in rd:
+        n = r.get("Kernel_Name", "")
+        if any(k in n for k in OURS):
+            agg[short(n)][r["Counter_Name"]].append(float(r["Counter_Value"]))
+with open(os.path.join(dst, "our_kernels_pmc_mean.csv"), "w", newline="") as o:
+    w = csv.writer(o)
+    w.writerow(["kernel", "counter", "dispatches", "mean_per_dispatch"])
+    for k in sorted(agg):
+        for c in sorted(agg[k]):
+            v = agg[k][c]
+            w.writerow([k, c, len(v), sum(v) / len(v)])
+print("summaries written to", dst)
