@@ -30,16 +30,6 @@ constexpr int KN_IMG = BK * BN;                      // floats
 constexpr int SMEM_FLOATS = 2 * ROW_IMG + 2 * ROW_IMG;
 constexpr int SMEM_BYTES = SMEM_FLOATS * 4;          // 67,584 B -> 2 workgroups / CU
 
-// Two workgroups share a CU (one wave of each per SIMD).  With equal priority they split the MFMA
-// pipe evenly, advance in lockstep and reach their barrier/staging phases together, leaving the
-// pipe idle.  Giving the co-resident workgroups different issue priorities breaks the symmetry:
-// the favoured one runs at full rate and the other fills its gaps.  HW_REG_HW_ID.TG_ID (bits
-// 19:16) numbers the workgroups resident on this CU; speed only, never correctness.
-__device__ __forceinline__ void stagger_priority_by_cu_slot() {
-    const unsigned tg = __builtin_amdgcn_s_getreg((3 << 11) | (16 << 6) | 4);
-    if (tg & 1u) __builtin_amdgcn_s_setprio(2);
-}
-
 __device__ __forceinline__ float* a_img(float* smem, int i) { return smem + i * ROW_IMG; }
 __device__ __forceinline__ float* b_img(float* smem, int i) { return smem + (2 + i) * ROW_IMG; }
 
@@ -179,9 +169,6 @@ __device__ __forceinline__ void write_rows_klo(float* __restrict__ img, const fl
     }
 }
 
-// ---- generic dense tile: acc = (scale*A[m0.., :]) x B ------------------------
-// A: [M x K] row-major (lda).  B_ROWS=false: B is [K x N] row-major (ldb), n contiguous.
-// B_ROWS=true: B is given as [N x K] row-major (ldb), i.e. acc = A x B^T.
 // ---- the software pipeline shared by every MFMA kernel ------------------------------------
 // Two register sets and two LDS buffers.  K-step t (reads LDS buffer t%2):
 //     issue the global loads of tile t+2 into register set t%2       (pinned ABOVE the MFMAs)
@@ -246,9 +233,12 @@ __device__ __forceinline__ void mfma_pipeline(int nk, float* smem, f32x16 (&acc)
     if (t < nk) kstep_pipelined<B_ROWS, 0>(smem, acc, wm, wn, last, last, load, write_a, write_b);
 }
 
-// ---- generic dense tile: acc = (scale*A[m0.., :]) x B ------------------------
+// ---- dense tile: acc = (scale*A[m0.., :]) x B ------------------------------------------------
 // A: [M x K] row-major (lda).  B_ROWS=false: B is [K x N] row-major (ldb), n contiguous.
 // B_ROWS=true: B is given as [N x K] row-major (ldb), i.e. acc = A x B^T.
+// (A finer interleave -- 16 slots of 4 MFMAs with one load / LDS-write chunk pinned after each --
+//  was measured 5 % SLOWER than the three-pin form on 4096^3, 126.7 vs 132.8 TF: the per-slot pins
+//  stop the compiler from batching LDS reads ahead of the MFMAs.)
 template <bool FAST_A, bool FAST_B, bool B_ROWS>
 __device__ __forceinline__ void gemm_tile(const float* __restrict__ A, long lda, const float* __restrict__ B,
                                           long ldb, int M, int N, int K, int m0, int n0, float a_scale,

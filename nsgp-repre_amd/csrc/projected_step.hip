@@ -15,19 +15,11 @@
 //           that share a P column panel land on the same XCD (blockIdx % 8).
 #include <algorithm>
 #include <cmath>
-#include <cstdlib>
 #include <new>
 #include <vector>
 
 #include "common.hpp"
 #include "gemm_core.hpp"
-
-#ifndef NSGP_STAGGER
-#define NSGP_STAGGER 0
-#endif
-#ifndef NSGP_ASSUME_ALIGNED
-#define NSGP_ASSUME_ALIGNED 0
-#endif
 
 namespace nsgp {
 
@@ -207,7 +199,6 @@ __global__ __launch_bounds__(256, 2) void nsgp_project_kernel(const TileDev* __r
                                                               const LayerDev* __restrict__ layers,
                                                               const DynBlock* __restrict__ dyn) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    if (NSGP_STAGGER) stagger_priority_by_cu_slot();
     const TileDev t = tiles[blockIdx.x];
     const LayerDev L = layers[t.layer];
     const float* A;
@@ -226,7 +217,7 @@ __global__ __launch_bounds__(256, 2) void nsgp_project_kernel(const TileDev* __r
     zero_acc(acc);
     // the grad pointer is only known at step time: a misaligned one (e.g. a view into a flat
     // bucket) takes the guarded scalar loader for the A operand only
-    if (!FAST || NSGP_ASSUME_ALIGNED || ((uintptr_t)A & 15u) == 0)
+    if (!FAST || ((uintptr_t)A & 15u) == 0)
         gemm_tile<FAST, FAST, false>(A, L.cols, L.proj, L.cols, L.rows, L.cols, L.cols, t.m0, t.n0, scale, smem, acc);
     else
         gemm_tile<false, true, false>(A, L.cols, L.proj, L.cols, L.rows, L.cols, L.cols, t.m0, t.n0, scale, smem, acc);
@@ -351,23 +342,13 @@ extern "C" int nsgp_plan_create(nsgp_plan_t** out, const nsgp_tensor_t* tensors,
             while (g1 < order.size() && ld[order[g1]].cols == ld[order[g0]].cols) ++g1;
             std::vector<TileDev> q[8];
             int rot = 0;
-            const char* ord_env = getenv("NSGP_TILE_ORDER");  // measurement knob: 0 = XCD queues (default)
-            const int ord = ord_env ? atoi(ord_env) : 0;
             for (size_t oi = g0; oi < g1; ++oi) {
                 const int li = order[oi];
                 if ((layer_fast[li] != 0) != (pass == 0)) continue;
                 const int mb = (ld[li].rows + BM - 1) / BM, nb = (ld[li].cols + BN - 1) / BN;
-                if (ord == 1) {         // plain: n fastest
-                    for (int m = 0; m < mb; ++m)
-                        for (int j = 0; j < nb; ++j) dst.push_back(TileDev{li, m * BM, j * BN, 0});
-                } else if (ord == 2) {  // plain: m fastest
-                    for (int j = 0; j < nb; ++j)
-                        for (int m = 0; m < mb; ++m) dst.push_back(TileDev{li, m * BM, j * BN, 0});
-                } else {
-                    for (int j = 0; j < nb; ++j)
-                        for (int m = 0; m < mb; ++m) q[(j + rot) & 7].push_back(TileDev{li, m * BM, j * BN, 0});
-                    rot += nb;
-                }
+                for (int j = 0; j < nb; ++j)
+                    for (int m = 0; m < mb; ++m) q[(j + rot) & 7].push_back(TileDev{li, m * BM, j * BN, 0});
+                rot += nb;
             }
             size_t pos[8] = {0, 0, 0, 0, 0, 0, 0, 0};
             size_t total = 0;

@@ -154,7 +154,7 @@ def test_two_task_run_keeps_old_features_fixed(N, dev):
         P = opt2.transforms[name]
         dW = (dict(net.named_parameters())[name].detach() - before[name]).view(16, -1)
         # dW lies in the row space of P (dW = U P): re-projecting changes nothing
-        Pn = P * P.norm()                                   # undo the backbone 1/||P||_F scale -> a projector
+        Pn = P * torch.trace(P)     # undo the backbone 1/||P0||_F scale: trace(P0/c) = rank/c = c for a projector
         assert _rel(dW @ Pn, dW) <= 1e-3
         # and it annihilates the dominant old-task input directions
         lam, Q = torch.linalg.eigh(cov[name])

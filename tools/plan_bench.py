@@ -30,6 +30,7 @@ def run(layers, label, steps=12):
     fl, by, tiles, nl = opt.plan_stats()
     print(f"{label:34s} tiles {tiles:5d}  update {u*1e3:7.1f} us  gemm {g*1e3:8.1f} us  {fl/g/1e9:6.1f} TF", flush=True)
 
+run([(4096, 4096)], "1x(4096,4096) = 1024 tiles")
 run([(512, 4096)] * 8, "8x(512,4096) = 1024 tiles")
 run([(512, 4608)] * 3, "3x(512,4608) = 432 tiles")
 run([(2048, 1024)] * 8, "8x(2048,1024) = 1024 tiles")
