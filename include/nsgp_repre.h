@@ -32,7 +32,7 @@ extern "C" {
 #define NSGP_ERR_WORKSPACE (-3) /* workspace too small */
 #define NSGP_ERR_LIMIT (-4)     /* a fixed capacity was exceeded (e.g. > NSGP_MAX_HYPER combos) */
 
-#define NSGP_ABI_VERSION 1
+#define NSGP_ABI_VERSION 2
 #define NSGP_MAX_HYPER 32 /* distinct hyper-parameter sets per plan step */
 
 int nsgp_abi_version(void);
@@ -72,6 +72,12 @@ typedef struct {
     int32_t rows;       /* Cout  = update.size(0)            (projected tensors only) */
     int32_t cols;       /* D     = numel / rows = Cin*kh*kw  (projected tensors only) */
     int32_t hyper;      /* index into the per-step hyper array */
+    int32_t rank;       /* low-rank form (optional): number of TOP eigenvectors r = first_col of the projector */
+    const float* basis; /* low-rank form (optional): V [cols x cols] row-major, eigenvectors in columns (descending);
+                           when non-NULL and 0 < 4*rank <= cols the step applies
+                           p += basis_scale * (u - (u U) U^T),  U = V[:, :rank]  ==  u @ (basis_scale * V_tail V_tail^T)
+                           in 4*Cout*D*r FLOP instead of 2*Cout*D^2; otherwise the dense `proj` is used */
+    float basis_scale;  /* 1/||P||_F for Frobenius-normalised projectors (SGD_NSCL.py:282-283), else 1 */
     int32_t reserved;
 } nsgp_tensor_t;
 
@@ -91,7 +97,8 @@ typedef struct {
     int32_t reserved;
 } nsgp_hyper_t;
 
-/* Device bytes of update workspace a plan needs (Adam kinds: sum of projected numel*4; SGD: 0). */
+/* Device bytes of workspace a plan needs (Adam kinds: the projected updates; low-rank layers: the
+ * [Cout x r] intermediates and their split-K slabs). */
 size_t nsgp_plan_workspace_bytes(const nsgp_tensor_t* tensors, int n_tensors, int optimizer);
 
 /* Build a plan: validates shapes, builds the cost-sorted, XCD-interleaved tile
@@ -111,6 +118,10 @@ int nsgp_plan_step(nsgp_plan_t* plan, float* const* grads, const nsgp_hyper_t* h
  * (sum 2*Cout*D^2; sum 4*D^2 + 5*4*numel). */
 int nsgp_plan_stats(const nsgp_plan_t* plan, double* gemm_flops, double* algorithmic_bytes,
                     int* n_tiles, int* n_projected);
+
+/* Layers that take the low-rank form and their FLOPs (sum 4*Cout*D*r), tile counts of its two phases. */
+int nsgp_plan_lowrank_stats(const nsgp_plan_t* plan, int* n_lowrank, double* lowrank_flops,
+                            int* n_tiles_p1, int* n_tiles_p2);
 
 /* Per-launch timing with HIP events recorded on the launch stream (measurement only): between
  * _begin and _end each nsgp_plan_step records 3 events; _end synchronises on them and returns

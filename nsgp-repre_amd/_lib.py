@@ -14,7 +14,8 @@ class TensorDesc(C.Structure):
     """nsgp_tensor_t"""
     _fields_ = [("param", C.c_void_p), ("state0", C.c_void_p), ("state1", C.c_void_p), ("state2", C.c_void_p),
                 ("proj", C.c_void_p), ("numel", C.c_int64), ("rows", C.c_int32), ("cols", C.c_int32),
-                ("hyper", C.c_int32), ("reserved", C.c_int32)]
+                ("hyper", C.c_int32), ("rank", C.c_int32), ("basis", C.c_void_p), ("basis_scale", C.c_float),
+                ("reserved", C.c_int32)]
 
 
 class Hyper(C.Structure):
@@ -38,6 +39,7 @@ SIGNATURES = {
     "nsgp_plan_destroy": (C.c_int, [C.c_void_p]),
     "nsgp_plan_step": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(Hyper), C.c_int, C.c_void_p]),
     "nsgp_plan_stats": (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    "nsgp_plan_lowrank_stats": (C.c_int, [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_double), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "nsgp_plan_profile_begin": (C.c_int, [C.c_void_p, C.c_int]),
     "nsgp_plan_profile_end": (C.c_int, [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_float), C.POINTER(C.c_float)]),
     "nsgp_project": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_int, C.c_void_p]),

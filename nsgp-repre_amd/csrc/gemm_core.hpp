@@ -169,6 +169,18 @@ __device__ __forceinline__ void write_rows_klo(float* __restrict__ img, const fl
     }
 }
 
+// k >= k_hi zeroed (low-rank projection: the operands' K extent is the rank r, loads run to the
+// next multiple of 32 inside valid memory)
+__device__ __forceinline__ void write_rows_khi(float* __restrict__ img, const float (&r)[4][4], int k0, int k_hi) {
+    const int t = threadIdx.x;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        float* dst = img + ((t >> 3) + 32 * j) * ROW_LD + (t & 7) * 4;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) dst[e] = (k0 + (t & 7) * 4 + e < k_hi) ? r[j][e] : 0.0f;
+    }
+}
+
 // ---- the software pipeline shared by every MFMA kernel ------------------------------------
 // Two register sets and two LDS buffers.  K-step t (reads LDS buffer t%2):
 //     issue the global loads of tile t+2 into register set t%2       (pinned ABOVE the MFMAs)

@@ -43,11 +43,19 @@ struct LayerDev {
     int tensor;
     int rows, cols;
     int hyper;
+    // low-rank form (rank > 0): V, r, T = (scale*S) U  [rows x rpad], its split-K slabs, 1/||P||_F
+    const float* basis;
+    float* T;
+    float* slabs;
+    int rank, rpad, nsplit;
+    float basis_scale;
 };
 
 struct TileDev {
-    int layer, m0, n0, pad;
+    int layer, m0, n0, pad;  // pad: split-K slice index (low-rank phase 1)
 };
+
+constexpr int LR_KCHUNK = 512;  // K extent of one low-rank phase-1 tile
 
 struct ChunkDev {
     int tensor;
@@ -238,6 +246,104 @@ __global__ __launch_bounds__(256, 2) void nsgp_project_single_kernel(const float
     else store_tile<FAST, false>(out, cols, rows, cols, m0, n0, acc);
 }
 
+// ---- low-rank form:  p += c * (u - (u U) U^T),  u = scale*S,  U = V[:, :r]  ------------------------
+// Same result as u @ (c * V_tail V_tail^T) up to the orthogonality error of V, in 4*Cout*D*r FLOP.
+// Phase 1: T = u U as split-K slabs (K chunks of 512 so that the skinny [Cout x r] product still fills
+// the chip); a deterministic reduce sums the slabs; phase 2: p += c*(u - T U^T), K = r.
+template <int OPT>
+__device__ __forceinline__ void lowrank_source(const LayerDev& L, const DynBlock* dyn, const float*& A, float& scale) {
+    if (OPT == NSGP_OPT_SGD) {
+        const nsgp_hyper_t& h = dyn->hyper[L.hyper];
+        A = (h.momentum != 0.0f && !h.nesterov) ? L.s0 : dyn->grads[L.tensor];
+        scale = -h.lr;
+    } else {
+        A = L.u;
+        scale = 1.0f;
+    }
+}
+
+template <int OPT>
+__global__ __launch_bounds__(256, 2) void nsgp_lowrank_p1_kernel(const TileDev* __restrict__ tiles,
+                                                                 const LayerDev* __restrict__ layers,
+                                                                 const DynBlock* __restrict__ dyn) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const TileDev t = tiles[blockIdx.x];
+    const LayerDev L = layers[t.layer];
+    const float* A;
+    float scale;
+    lowrank_source<OPT>(L, dyn, A, scale);
+    const int k0 = t.pad * LR_KCHUNK;
+    const int k1 = min(k0 + LR_KCHUNK, L.cols);
+    f32x16 acc[2][2];
+    zero_acc(acc);
+    float ra[2][4][4], rb[2][4][4];
+    const bool a_fast = ((uintptr_t)A & 15u) == 0;
+    mfma_pipeline<false>(
+        (k1 - k0) / BK, smem, acc,
+        [&](int kt, auto s) {
+            constexpr int S = decltype(s)::value;
+            if (a_fast) stage_rows<true>(A, L.cols, L.rows, L.cols, t.m0, k0 + kt * BK, ra[S]);
+            else stage_rows<false>(A, L.cols, L.rows, L.cols, t.m0, k0 + kt * BK, ra[S]);
+            stage_kn<true>(L.basis, L.cols, L.cols, L.cols, k0 + kt * BK, t.n0, rb[S]);
+        },
+        [&](float* img, int, auto s) { write_rows(img, ra[decltype(s)::value], scale); },
+        [&](float* img, int, auto s) { write_kn(img, rb[decltype(s)::value]); });
+    store_tile<true, false>(L.slabs + (long)t.pad * L.rows * L.rpad, L.rpad, L.rows, L.rpad, t.m0, t.n0, acc);
+}
+
+__global__ __launch_bounds__(256) void nsgp_lowrank_reduce_kernel(const ChunkDev* __restrict__ chunks,
+                                                                  const LayerDev* __restrict__ layers) {
+    const ChunkDev c = chunks[blockIdx.x];
+    const LayerDev L = layers[c.tensor];
+    const long n = (long)L.rows * L.rpad;
+    const long end = (c.start + CHUNK < n) ? c.start + CHUNK : n;
+    for (long i = c.start + (long)threadIdx.x * 4; i < end; i += 256 * 4) {   // rpad % 128 == 0 -> n % 4 == 0
+        f32x4 s = *(const gf32x4*)(L.slabs + i);
+        for (int k = 1; k < L.nsplit; ++k) s += *(const gf32x4*)(L.slabs + (long)k * n + i);
+        *(gf32x4*)(L.T + i) = s;
+    }
+}
+
+template <int OPT>
+__global__ __launch_bounds__(256, 2) void nsgp_lowrank_p2_kernel(const TileDev* __restrict__ tiles,
+                                                                 const LayerDev* __restrict__ layers,
+                                                                 const DynBlock* __restrict__ dyn) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const TileDev t = tiles[blockIdx.x];
+    const LayerDev L = layers[t.layer];
+    const float* A;
+    float scale;
+    lowrank_source<OPT>(L, dyn, A, scale);
+    f32x16 acc[2][2];
+    zero_acc(acc);
+    float ra[2][4][4], rb[2][4][4];
+    mfma_pipeline<true>(
+        (L.rank + BK - 1) / BK, smem, acc,
+        [&](int kt, auto s) {
+            constexpr int S = decltype(s)::value;
+            stage_rows<true>(L.T, L.rpad, L.rows, L.rpad, t.m0, kt * BK, ra[S]);          // T[m][k]
+            stage_rows<true>(L.basis, L.cols, L.cols, L.cols, t.n0, kt * BK, rb[S]);       // U[n][k] = V[n][k]
+        },
+        [&](float* img, int kt, auto s) { write_rows_khi(img, ra[decltype(s)::value], kt * BK, L.rank); },
+        [&](float* img, int kt, auto s) { write_rows_khi(img, rb[decltype(s)::value], kt * BK, L.rank); });
+    // p += c * (scale*S - T U^T)
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const gfloat* Ag = as_global(A);
+    gfloat* Pg = as_global(L.p);
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni) {
+            const int col = t.n0 + wn * 64 + ni * 32 + (lane & 31);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const long idx = (long)(t.m0 + wm * 64 + mi * 32 + acc_row(r, lane)) * L.cols + col;
+                Pg[idx] = Pg[idx] + L.basis_scale * (scale * Ag[idx] - acc[mi][ni][r]);
+            }
+        }
+}
+
 // ---- host: plan ---------------------------------------------------------------
 template <typename K>
 static int enable_big_lds(K kernel) {
@@ -259,7 +365,10 @@ struct nsgp_plan {
     double gemm_flops = 0, bytes = 0;
     TensorDev* d_tensors = nullptr;
     LayerDev* d_layers = nullptr;
-    TileDev* d_tiles = nullptr;  // fast tiles first, generic after
+    TileDev* d_tiles = nullptr;  // dense fast tiles | dense generic tiles | low-rank phase-1 | phase-2
+    int n_tiles_lr1 = 0, n_tiles_lr2 = 0, n_chunks_lr = 0, n_lowrank = 0;
+    double lowrank_flops = 0;
+    ChunkDev* d_chunks_lr = nullptr;
     ChunkDev* d_chunks = nullptr;
     size_t dyn_bytes = 0;
     char* h_dyn[NSLOT] = {nullptr, nullptr, nullptr, nullptr};  // pinned
@@ -276,11 +385,24 @@ static bool tensor_fast(const nsgp_tensor_t& t) {
     return t.rows % BM == 0 && t.cols % BN == 0 && t.cols % BK == 0 && aligned16(t.proj);
 }
 
+// low-rank form: needs the fast shape, an aligned basis, and r <= D/4 (else the dense GEMM is cheaper)
+static bool tensor_lowrank(const nsgp_tensor_t& t) {
+    return t.basis && t.rank > 0 && 4 * (long)t.rank <= t.cols && t.rows % BM == 0 && t.cols % BN == 0 &&
+           aligned16(t.basis) && aligned16(t.param) && t.proj;
+}
+static int lr_rpad(int rank) { return (rank + BN - 1) / BN * BN; }
+static int lr_nsplit(int cols) { return (cols + LR_KCHUNK - 1) / LR_KCHUNK; }
+static size_t pad256(size_t x) { return (x + 255) & ~(size_t)255; }
+
 extern "C" size_t nsgp_plan_workspace_bytes(const nsgp_tensor_t* tensors, int n, int optimizer) {
-    if (optimizer != NSGP_OPT_ADAM || !tensors) return 0;
+    if (!tensors) return 0;
     size_t s = 0;
-    for (int i = 0; i < n; ++i)
-        if (tensors[i].proj) s += ((size_t)tensors[i].numel * 4 + 255) & ~(size_t)255;
+    for (int i = 0; i < n; ++i) {
+        const nsgp_tensor_t& t = tensors[i];
+        if (!t.proj) continue;
+        if (optimizer == NSGP_OPT_ADAM) s += pad256((size_t)t.numel * 4);
+        if (tensor_lowrank(t)) s += pad256((size_t)t.rows * lr_rpad(t.rank) * 4) * (1 + lr_nsplit(t.cols));
+    }
     return s;
 }
 
@@ -297,7 +419,8 @@ extern "C" int nsgp_plan_create(nsgp_plan_t** out, const nsgp_tensor_t* tensors,
     std::vector<LayerDev> ld;
     std::vector<ChunkDev> cd;
     std::vector<char> layer_fast;
-    double flops = 0, bytes = 0;
+    double flops = 0, bytes = 0, lr_flops = 0;
+    int n_lowrank = 0;
     size_t ws_off = 0;
     for (int i = 0; i < n; ++i) {
         const nsgp_tensor_t& t = tensors[i];
@@ -314,7 +437,21 @@ extern "C" int nsgp_plan_create(nsgp_plan_t** out, const nsgp_tensor_t* tensors,
                 d.u = reinterpret_cast<float*>(static_cast<char*>(workspace) + ws_off);
                 ws_off += ((size_t)t.numel * 4 + 255) & ~(size_t)255;
             }
-            ld.push_back(LayerDev{t.param, t.state0, d.u, t.proj, i, t.rows, t.cols, t.hyper});
+            LayerDev L{t.param, t.state0, d.u, t.proj, i, t.rows, t.cols, t.hyper, nullptr, nullptr, nullptr, 0, 0, 0, 1.0f};
+            if (tensor_lowrank(t)) {
+                L.basis = t.basis;
+                L.rank = t.rank;
+                L.rpad = lr_rpad(t.rank);
+                L.nsplit = lr_nsplit(t.cols);
+                L.basis_scale = t.basis_scale;
+                const size_t one = pad256((size_t)t.rows * L.rpad * 4);
+                L.T = reinterpret_cast<float*>(static_cast<char*>(workspace) + ws_off);
+                L.slabs = reinterpret_cast<float*>(static_cast<char*>(workspace) + ws_off + one);
+                ws_off += one * (1 + L.nsplit);
+                lr_flops += 4.0 * t.rows * (double)t.cols * t.rank;
+                ++n_lowrank;
+            }
+            ld.push_back(L);
             layer_fast.push_back(tensor_fast(t) && aligned16(t.param) && aligned16(t.state0) ? 1 : 0);
             flops += 2.0 * t.rows * (double)t.cols * t.cols;
             bytes += 4.0 * (double)t.cols * t.cols;
@@ -344,7 +481,7 @@ extern "C" int nsgp_plan_create(nsgp_plan_t** out, const nsgp_tensor_t* tensors,
             int rot = 0;
             for (size_t oi = g0; oi < g1; ++oi) {
                 const int li = order[oi];
-                if ((layer_fast[li] != 0) != (pass == 0)) continue;
+                if ((layer_fast[li] != 0) != (pass == 0) || ld[li].rank > 0) continue;
                 const int mb = (ld[li].rows + BM - 1) / BM, nb = (ld[li].cols + BN - 1) / BN;
                 for (int j = 0; j < nb; ++j)
                     for (int m = 0; m < mb; ++m) q[(j + rot) & 7].push_back(TileDev{li, m * BM, j * BN, 0});
@@ -381,8 +518,34 @@ extern "C" int nsgp_plan_create(nsgp_plan_t** out, const nsgp_tensor_t* tensors,
     P->n_tiles_generic = (int)gen_tiles.size();
     P->gemm_flops = flops;
     P->bytes = bytes;
+    // low-rank tiles: phase 1 (T slabs: [rows x rpad] per K chunk), phase 2 (p tiles, K = r); both
+    // in descending-cost order (phase 1 tiles all cost one K chunk; phase 2 cost ~ r)
+    std::vector<TileDev> lr1, lr2;
+    std::vector<ChunkDev> lr_chunks;
+    {
+        std::vector<int> lo;
+        for (size_t li = 0; li < ld.size(); ++li)
+            if (ld[li].rank > 0) lo.push_back((int)li);
+        std::stable_sort(lo.begin(), lo.end(), [&](int a, int b) { return ld[a].rank > ld[b].rank; });
+        for (int li : lo) {
+            const LayerDev& L = ld[li];
+            for (int ks = 0; ks < L.nsplit; ++ks)
+                for (int j = 0; j < L.rpad / BN; ++j)
+                    for (int m = 0; m < L.rows / BM; ++m) lr1.push_back(TileDev{li, m * BM, j * BN, ks});
+            for (int j = 0; j < L.cols / BN; ++j)
+                for (int m = 0; m < L.rows / BM; ++m) lr2.push_back(TileDev{li, m * BM, j * BN, 0});
+            for (long st = 0; st < (long)L.rows * L.rpad; st += CHUNK) lr_chunks.push_back(ChunkDev{li, 0, st});
+        }
+    }
     std::vector<TileDev> all_tiles(fast_tiles);
     all_tiles.insert(all_tiles.end(), gen_tiles.begin(), gen_tiles.end());
+    all_tiles.insert(all_tiles.end(), lr1.begin(), lr1.end());
+    all_tiles.insert(all_tiles.end(), lr2.begin(), lr2.end());
+    P->n_tiles_lr1 = (int)lr1.size();
+    P->n_tiles_lr2 = (int)lr2.size();
+    P->n_chunks_lr = (int)lr_chunks.size();
+    P->n_lowrank = n_lowrank;
+    P->lowrank_flops = lr_flops;
     P->dyn_bytes = (sizeof(nsgp_hyper_t) * NSGP_MAX_HYPER + sizeof(float*) * (size_t)n + 255) & ~(size_t)255;
 
 #define PLAN_HIP(call)                                                                               \
@@ -397,6 +560,10 @@ extern "C" int nsgp_plan_create(nsgp_plan_t** out, const nsgp_tensor_t* tensors,
     PLAN_HIP(hipMemcpy(P->d_tensors, td.data(), sizeof(TensorDev) * td.size(), hipMemcpyHostToDevice));
     PLAN_HIP(hipMalloc(&P->d_chunks, sizeof(ChunkDev) * cd.size()));
     PLAN_HIP(hipMemcpy(P->d_chunks, cd.data(), sizeof(ChunkDev) * cd.size(), hipMemcpyHostToDevice));
+    if (!lr_chunks.empty()) {
+        PLAN_HIP(hipMalloc(&P->d_chunks_lr, sizeof(ChunkDev) * lr_chunks.size()));
+        PLAN_HIP(hipMemcpy(P->d_chunks_lr, lr_chunks.data(), sizeof(ChunkDev) * lr_chunks.size(), hipMemcpyHostToDevice));
+    }
     if (!ld.empty()) {
         PLAN_HIP(hipMalloc(&P->d_layers, sizeof(LayerDev) * ld.size()));
         PLAN_HIP(hipMemcpy(P->d_layers, ld.data(), sizeof(LayerDev) * ld.size(), hipMemcpyHostToDevice));
@@ -410,7 +577,9 @@ extern "C" int nsgp_plan_create(nsgp_plan_t** out, const nsgp_tensor_t* tensors,
     }
 #undef PLAN_HIP
     int rc;
-    if ((rc = enable_big_lds(nsgp_project_kernel<NSGP_OPT_SGD, true>)) || (rc = enable_big_lds(nsgp_project_kernel<NSGP_OPT_SGD, false>)) ||
+    if ((rc = enable_big_lds(nsgp_lowrank_p1_kernel<NSGP_OPT_SGD>)) || (rc = enable_big_lds(nsgp_lowrank_p1_kernel<NSGP_OPT_ADAM>)) ||
+        (rc = enable_big_lds(nsgp_lowrank_p2_kernel<NSGP_OPT_SGD>)) || (rc = enable_big_lds(nsgp_lowrank_p2_kernel<NSGP_OPT_ADAM>)) ||
+        (rc = enable_big_lds(nsgp_project_kernel<NSGP_OPT_SGD, true>)) || (rc = enable_big_lds(nsgp_project_kernel<NSGP_OPT_SGD, false>)) ||
         (rc = enable_big_lds(nsgp_project_kernel<NSGP_OPT_ADAM, true>)) || (rc = enable_big_lds(nsgp_project_kernel<NSGP_OPT_ADAM, false>))) {
         nsgp_plan_destroy(P);
         return rc;
@@ -431,16 +600,26 @@ extern "C" int nsgp_plan_destroy(nsgp_plan_t* P) {
     if (P->d_layers) (void)hipFree(P->d_layers);
     if (P->d_tiles) (void)hipFree(P->d_tiles);
     if (P->d_chunks) (void)hipFree(P->d_chunks);
+    if (P->d_chunks_lr) (void)hipFree(P->d_chunks_lr);
     delete P;
     return NSGP_OK;
 }
 
 extern "C" int nsgp_plan_stats(const nsgp_plan_t* P, double* gemm_flops, double* bytes, int* n_tiles, int* n_proj) {
     if (!P) return fail(NSGP_ERR_INVALID, "nsgp_plan_stats: null plan");
-    if (gemm_flops) *gemm_flops = P->gemm_flops;
+    if (gemm_flops) *gemm_flops = P->gemm_flops;  // the dense form's 2*Cout*D^2 for every projected layer
     if (bytes) *bytes = P->bytes;
     if (n_tiles) *n_tiles = P->n_tiles_fast + P->n_tiles_generic;
     if (n_proj) *n_proj = P->n_layers;
+    return NSGP_OK;
+}
+
+extern "C" int nsgp_plan_lowrank_stats(const nsgp_plan_t* P, int* n_lowrank, double* lowrank_flops, int* n_tiles_p1, int* n_tiles_p2) {
+    if (!P) return fail(NSGP_ERR_INVALID, "nsgp_plan_lowrank_stats: null plan");
+    if (n_lowrank) *n_lowrank = P->n_lowrank;
+    if (lowrank_flops) *lowrank_flops = P->lowrank_flops;
+    if (n_tiles_p1) *n_tiles_p1 = P->n_tiles_lr1;
+    if (n_tiles_p2) *n_tiles_p2 = P->n_tiles_lr2;
     return NSGP_OK;
 }
 
@@ -483,6 +662,22 @@ extern "C" int nsgp_plan_step(nsgp_plan_t* P, float* const* grads, const nsgp_hy
             hipLaunchKernelGGL((nsgp_project_kernel<NSGP_OPT_SGD, false>), dim3(P->n_tiles_generic), dim3(THREADS), SMEM_BYTES, stream, gt, P->d_layers, d);
         else
             hipLaunchKernelGGL((nsgp_project_kernel<NSGP_OPT_ADAM, false>), dim3(P->n_tiles_generic), dim3(THREADS), SMEM_BYTES, stream, gt, P->d_layers, d);
+        NSGP_LAUNCH_CHECK();
+    }
+    if (P->n_tiles_lr1 > 0) {
+        const TileDev* t1 = P->d_tiles + P->n_tiles_fast + P->n_tiles_generic;
+        const TileDev* t2 = t1 + P->n_tiles_lr1;
+        if (P->optimizer == NSGP_OPT_SGD)
+            hipLaunchKernelGGL(nsgp_lowrank_p1_kernel<NSGP_OPT_SGD>, dim3(P->n_tiles_lr1), dim3(THREADS), SMEM_BYTES, stream, t1, P->d_layers, d);
+        else
+            hipLaunchKernelGGL(nsgp_lowrank_p1_kernel<NSGP_OPT_ADAM>, dim3(P->n_tiles_lr1), dim3(THREADS), SMEM_BYTES, stream, t1, P->d_layers, d);
+        NSGP_LAUNCH_CHECK();
+        hipLaunchKernelGGL(nsgp_lowrank_reduce_kernel, dim3(P->n_chunks_lr), dim3(256), 0, stream, P->d_chunks_lr, P->d_layers);
+        NSGP_LAUNCH_CHECK();
+        if (P->optimizer == NSGP_OPT_SGD)
+            hipLaunchKernelGGL(nsgp_lowrank_p2_kernel<NSGP_OPT_SGD>, dim3(P->n_tiles_lr2), dim3(THREADS), SMEM_BYTES, stream, t2, P->d_layers, d);
+        else
+            hipLaunchKernelGGL(nsgp_lowrank_p2_kernel<NSGP_OPT_ADAM>, dim3(P->n_tiles_lr2), dim3(THREADS), SMEM_BYTES, stream, t2, P->d_layers, d);
         NSGP_LAUNCH_CHECK();
     }
     if (prof) {

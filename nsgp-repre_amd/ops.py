@@ -40,7 +40,8 @@ def project(a: torch.Tensor, proj: torch.Tensor, scale: float = 1.0, out: torch.
     return out
 
 
-def build_projector(V: torch.Tensor, first_col: int, normalise: bool, out: torch.Tensor = None) -> torch.Tensor:
+def build_projector(V: torch.Tensor, first_col: int, normalise: bool, out: torch.Tensor = None,
+                    return_norm: bool = False):
     """``P = V[:, first_col:] @ V[:, first_col:].T`` (``/ ||P||_F`` if normalise) --
     mmdet/engine/optimizers/SGD_NSCL.py:270-285."""
     lib = _lib.load_library()
@@ -53,6 +54,9 @@ def build_projector(V: torch.Tensor, first_col: int, normalise: bool, out: torch
     scratch = torch.empty(nbytes, dtype=torch.uint8, device=V.device)
     _lib.check(lib.nsgp_build_projector(_dev(V, "V"), D, int(first_col), int(bool(normalise)), _dev(out, "P"),
                                         C.c_void_p(scratch.data_ptr()), nbytes, _stream()), "nsgp_build_projector")
+    if return_norm:   # ||P||_F before the division (fp32, slot NORM_BLOCKS of the scratch), as a 0-d GPU tensor
+        norm = scratch[1024 * 8:1024 * 8 + 4].view(torch.float32)[0] if normalise else torch.ones((), device=V.device)
+        return out, norm
     return out
 
 

@@ -37,6 +37,10 @@ class NSCLOptimizerBase(Optimizer):
         self.count = 0
         #: mirror the reference's in-place mutation of ``p.grad`` (weight decay / Nesterov add)
         self.mutate_grad = True
+        #: opt-in: apply projectors built by get_transforms in their low-rank form
+        #: p += c*(u - (u U)U^T) (4*Cout*D*r FLOP) when r <= D/4; the dense u @ P is the parity path
+        self.low_rank = False
+        self._basis = {}
         self._plans = []
         self._plan_key = None
         self._workspaces = []
@@ -108,8 +112,17 @@ class NSCLOptimizerBase(Optimizer):
             kept = sv.shape[0] - first
             logger.info("%s: reserving basis %d/%d; cond: %s, radio:%s", n, kept, sv.shape[0],
                         float(sv[0] / sv[first]), float(sv[first:].sum() / sv.sum()))
-            V = self.eigens[n]["eigen_vector"]
-            self.transforms[n] = ops.build_projector(V, first, self._normalise(n)).detach_()
+            self.set_basis(n, self.eigens[n]["eigen_vector"], first)
+
+    def set_basis(self, name: str, V: torch.Tensor, rank: int, normalise=None):
+        """Install the projector of one parameter from an orthonormal eigenbasis: ``transforms[name] =
+        V[:, rank:] V[:, rank:]^T`` (Frobenius-normalised per the optimizer's rule) built by the HIP
+        SYRK kernel, and remember ``(V, rank)`` so that ``low_rank=True`` can apply it as
+        ``u - (u U) U^T``."""
+        normalise = self._normalise(name) if normalise is None else normalise
+        P, norm = ops.build_projector(V, int(rank), normalise, return_norm=True)
+        self.transforms[name] = P.detach_()
+        self._basis[name] = dict(V=V, rank=int(rank), norm=norm, P_ptr=P.data_ptr())
         self._plan_key = None  # new projector buffers -> new plan
 
     # ------------------------------------------------------------------ step
@@ -160,6 +173,11 @@ class NSCLOptimizerBase(Optimizer):
                                            f"{tuple(P.shape)} {P.dtype} {P.device}")
                     d.proj = P.data_ptr()
                     d.rows, d.cols = rows, cols
+                    b = self._basis.get(n)
+                    if self.low_rank and b is not None and b["P_ptr"] == P.data_ptr() and b["V"].is_contiguous():
+                        d.basis = b["V"].data_ptr()          # only for projectors this optimizer built itself
+                        d.rank = int(b["rank"])
+                        d.basis_scale = 1.0 / float(b["norm"])
                 else:
                     d.proj = None
             nbytes = lib.nsgp_plan_workspace_bytes(descs, len(sub), self._kind)
@@ -179,6 +197,16 @@ class NSCLOptimizerBase(Optimizer):
             f, b, t, n = C.c_double(), C.c_double(), C.c_int(), C.c_int()
             _lib.check(lib.nsgp_plan_stats(plan["handle"], C.byref(f), C.byref(b), C.byref(t), C.byref(n)))
             tot = [tot[0] + f.value, tot[1] + b.value, tot[2] + t.value, tot[3] + n.value]
+        return tuple(tot)
+
+    def lowrank_stats(self):
+        """(n_lowrank_layers, lowrank_flops, n_tiles_phase1, n_tiles_phase2) over the current plans."""
+        lib = _lib.load_library()
+        tot = [0, 0.0, 0, 0]
+        for plan in self._plans:
+            n, f, a, b = C.c_int(), C.c_double(), C.c_int(), C.c_int()
+            _lib.check(lib.nsgp_plan_lowrank_stats(plan["handle"], C.byref(n), C.byref(f), C.byref(a), C.byref(b)))
+            tot = [tot[0] + n.value, tot[1] + f.value, tot[2] + a.value, tot[3] + b.value]
         return tuple(tot)
 
     def profile_begin(self, max_steps=1024):
@@ -227,7 +255,7 @@ class NSCLOptimizerBase(Optimizer):
                 key.append((p.data_ptr(), gi, P.data_ptr() if isinstance(P, torch.Tensor) else 0, bool(group["svd"])))
         if not entries:
             return loss
-        key = tuple(key)
+        key = (tuple(key), bool(self.low_rank))
         if key != self._plan_key:
             self._build_plans(entries)
             self._plan_key = key

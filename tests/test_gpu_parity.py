@@ -307,3 +307,59 @@ def test_full_r50_table_one_step_vs_torch_gpu(N, dev):
             upd = (upd.view(upd.shape[0], -1) @ Ps[n]).view_as(upd)
         exp = p0 + upd
         assert _rel(p - p0, exp - p0) <= 2e-5, n
+
+
+# ------------------------------------------------------------------ low-rank form (opt-in)
+@pytest.mark.parametrize("kind", ["sgd", "adamw"])
+def test_low_rank_form_matches_dense_form(N, dev, kind):
+    """``low_rank=True`` applies p += c*(u - (u U)U^T) instead of u @ P: same optimizer, same
+    projectors, two parameter copies -> the applied updates must agree within the 1e-5 gate, and
+    the layers that qualify (r <= D/4, 128-multiples) must really take the low-rank route."""
+    shapes = {"backbone.a.weight": (256, 128, 3, 3), "neck.b.weight": (128, 512, 1, 1), "backbone.c.weight": (128, 256, 1, 1),
+              "backbone.small.weight": (16, 8, 3, 3), "backbone.bn.weight": (256,)}
+    gen = torch.Generator().manual_seed(5)
+    init = {n: torch.randn(s, generator=gen) * 0.02 for n, s in shapes.items()}
+    covs = {}
+    for i, (n, s) in enumerate(shapes.items()):
+        if len(s) == 4:
+            D = s[1] * s[2] * s[3]
+            covs[n] = torch.from_numpy(I.covariance_like(D, 40 + i, rows_mult=2)).to(dev)
+    results = {}
+    for low in (False, True):
+        params = [torch.nn.Parameter(init[n].clone().to(dev)) for n in shapes]
+        opt = (N.SGDNSCL(params, lr=0.02, momentum=0.9, weight_decay=1e-4, svd=True) if kind == "sgd"
+               else N.AdamWNSCL(params, lr=1e-3, weight_decay=0.05, svd=True))
+        opt.param_groups[0]["names"] = list(shapes)
+        opt.low_rank = low
+        opt.get_eigens(covs)
+        opt.get_transforms(offset=0.0)
+        g2 = torch.Generator().manual_seed(9)
+        for step in range(3):
+            for p in params:
+                p.grad = torch.randn(p.shape, generator=g2).to(dev)
+            opt.step()
+        torch.cuda.synchronize()
+        n_lr, lr_flops, t1, t2 = opt.lowrank_stats()
+        results[low] = ([p.detach().cpu() for p in params], n_lr, {n: opt._basis[n]["rank"] for n in opt._basis})
+    (dense, n0, ranks), (lowr, n1, _) = results[False], results[True]
+    assert n0 == 0
+    qualifies = [n for n, s in shapes.items() if len(s) == 4 and s[0] % 128 == 0 and (s[1] * s[2] * s[3]) % 128 == 0
+                 and 0 < 4 * ranks[n] <= s[1] * s[2] * s[3]]
+    assert n1 == len(qualifies) >= 2, (n1, qualifies, ranks)
+    for n, a, b in zip(shapes, dense, lowr):
+        upd = (a.double() - init[n].double())
+        allowed = REL * upd.abs().max().item() + 2 * 2.0 ** -23 * a.abs().max().item()
+        assert (a.double() - b.double()).abs().max().item() <= allowed, (kind, n)
+
+
+def test_set_basis_builds_the_projector(N, dev):
+    D, r = 256, 24
+    Q, _ = torch.linalg.qr(torch.randn(D, D, generator=torch.Generator().manual_seed(3)))
+    p = torch.nn.Parameter(torch.zeros(128, D, 1, 1, device=dev))
+    opt = N.SGDNSCL([p], lr=0.1, svd=True)
+    opt.param_groups[0]["names"] = ["backbone.w.weight"]
+    opt.set_basis("backbone.w.weight", Q.contiguous().to(dev), r)
+    ref = Q[:, r:] @ Q[:, r:].t()
+    ref = ref / ref.norm()
+    assert _rel(opt.transforms["backbone.w.weight"], ref) <= REL
+    assert abs(float(opt._basis["backbone.w.weight"]["norm"]) - (D - r) ** 0.5) <= 1e-3
