@@ -196,6 +196,8 @@ __device__ __forceinline__ void write_rows_khi(float* __restrict__ img, const fl
 // VMEM reads and MFMAs from crossing the first pin and VALU / DS writes from crossing the
 // others; LDS reads and SALU still move freely.  RB is a template constant so LDS reads and
 // writes are provably disjoint ranges and register sets are statically indexed.
+// (Where the LDS writes sit inside the K-step -- between MFMA quarters as here, all before the
+//  MFMAs, or all after them -- measured the same within 2 % on 4096^3: 132.4 / 132.4 / 129.7 TF.)
 constexpr int SCHED_PIN_VMEM_READ = 0x2 | 0x4 | 0x100;   // VALU, SALU, DS-read may cross
 constexpr int SCHED_PIN_STAGING = 0x4 | 0x8 | 0x100;     // SALU, MFMA, DS-read may cross
 

@@ -16,7 +16,9 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from ..registry import MODELS, register
+from .. import ops
 from .prototype_bank import build_prototype_bank
+from .roi_dump import RoIDump
 
 try:  # pragma: no cover - mmdet is absent in this image
     from mmdet.models.roi_heads.standard_roi_head import StandardRoIHead as _Base
@@ -90,22 +92,81 @@ class PrototypeReplay:
         return losses
 
 
+def _init_base(self, bbox_roi_extractor, bbox_head, mask_roi_extractor, mask_head, shared_head, train_cfg, test_cfg,
+               init_cfg):
+    if _HAVE_MMDET:  # pragma: no cover
+        _Base.__init__(self, bbox_roi_extractor, bbox_head, mask_roi_extractor, mask_head, shared_head, train_cfg,
+                       test_cfg, init_cfg)
+    else:
+        nn.Module.__init__(self)
+        if isinstance(bbox_head, dict):
+            bbox_head = MODELS.build(bbox_head)
+        self.bbox_head = bbox_head
+        self.train_cfg, self.test_cfg = train_cfg, test_cfg
+
+
 @register(MODELS)
-class StandardMultiPrototypeReplayHead(PrototypeReplay, _Base):
+class StandardRoIReplayHead(RoIDump, _Base):
+    """Raw-RoI replay against the teacher (head:30-104): 64 random stored RoIs per step, MSE between the
+    student's and the teacher's class scores.  ``teacher_model`` is attached by the runner (runner:533)."""
+
+    def __init__(self, bbox_roi_extractor=None, bbox_head=None, mask_roi_extractor=None, mask_head=None,
+                 shared_head=None, train_cfg=None, test_cfg=None, init_cfg=None, previous_path=None):
+        _init_base(self, bbox_roi_extractor, bbox_head, mask_roi_extractor, mask_head, shared_head, train_cfg, test_cfg,
+                   init_cfg)
+        self.replay = False
+        if previous_path is not None and osp.exists(previous_path):
+            self.replay = True
+            (self.bbox_featss, self.cls_targets, self.cls_weights, self.bbox_targets, self.bbox_weights,
+             self.roiss) = torch.load(osp.join(previous_path, "rois_etc.pth"), weights_only=True)
+
+    def replay_loss(self, bbox_feats, sampling_results=None, rois=None) -> dict:
+        if getattr(self, "with_shared_head", False):
+            bbox_feats = self.shared_head(bbox_feats)
+        cls_score, bbox_pred = self.bbox_head(bbox_feats)
+        teacher_cls_score, _ = self.teacher_model.bbox_head(bbox_feats)
+        return dict(cls_score=cls_score, bbox_pred=bbox_pred, bbox_feats=bbox_feats,
+                    replay_loss=dict(replay_loss_cls=F.mse_loss(cls_score, teacher_cls_score)))
+
+    def add_replay_loss(self, losses: dict) -> dict:
+        if self.replay:
+            dev = next(self.parameters()).device
+            pick = torch.randperm(self.bbox_featss.shape[0])[:64].to(self.bbox_featss.device)       # head:56
+            losses.update(self.replay_loss(self.bbox_featss[pick].to(dev))["replay_loss"])
+        return losses
+
+
+@register(MODELS)
+class StandardPrototypeReplayHead(PrototypeReplay, RoIDump, _Base):
+    """One (coarse) prototype per old class, label = row index (head:206-300)."""
+
+    def __init__(self, bbox_roi_extractor=None, bbox_head=None, mask_roi_extractor=None, mask_head=None,
+                 shared_head=None, train_cfg=None, test_cfg=None, init_cfg=None, previous_path=None, task_id=1,
+                 task_split=(0, 10, 20)):
+        _init_base(self, bbox_roi_extractor, bbox_head, mask_roi_extractor, mask_head, shared_head, train_cfg, test_cfg,
+                   init_cfg)
+        self.replay, self.task_split, self.task_id = False, list(task_split), task_id
+        if previous_path is not None and osp.exists(previous_path):
+            assert task_id != 1
+            self.replay = True
+            dev = torch.device("cuda", torch.cuda.current_device())
+            rois = torch.load(osp.join(previous_path, "rois_etc.pth"), map_location=dev, weights_only=True)
+            feats, self.cls_targets = rois[0].reshape(rois[0].shape[0], -1).float().contiguous(), rois[1]
+            rows = [ops.masked_mean(feats[self.cls_targets == c].contiguous())
+                    for c in range(self.task_split[0], self.task_split[task_id - 1])]
+            self.bbox_featss = torch.cat(rows, dim=0)
+            self.tmp_label = torch.arange(self.bbox_featss.shape[0], device=dev)                     # head:293
+
+
+@register(MODELS)
+class StandardMultiPrototypeReplayHead(PrototypeReplay, RoIDump, _Base):
     """Same keywords as the reference (head:377-390)."""
 
     def __init__(self, bbox_roi_extractor=None, bbox_head=None, mask_roi_extractor=None, mask_head=None,
                  shared_head=None, train_cfg=None, test_cfg=None, init_cfg=None, previous_path=None, task_id=1,
                  task_split=(0, 10, 20), max_prototype=10, work_dir=None):
-        if _HAVE_MMDET:  # pragma: no cover
-            super().__init__(bbox_roi_extractor, bbox_head, mask_roi_extractor, mask_head, shared_head, train_cfg,
-                             test_cfg, init_cfg)
-        else:
-            nn.Module.__init__(self)
-            if isinstance(bbox_head, dict):
-                bbox_head = MODELS.build(bbox_head)
-            self.bbox_head = bbox_head
-            self.train_cfg, self.test_cfg = train_cfg, test_cfg
+        _init_base(self, bbox_roi_extractor, bbox_head, mask_roi_extractor, mask_head, shared_head, train_cfg, test_cfg,
+                   init_cfg)
         self.init_prototype_replay(previous_path, task_id, task_split, max_prototype)
 
     def loss(self, x, rpn_results_list, batch_data_samples) -> dict:

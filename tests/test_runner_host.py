@@ -37,7 +37,8 @@ class TinyNet(nn.Module):
 def test_registry_has_every_reference_name(N):
     r = N.registry
     assert r.RUNNERS.get("BRNullSpaceRunner") is N.runner.BRNullSpaceRunner
-    for name in ("FasterRCNNRoIReplay", "StandardMultiPrototypeReplayHead", "Shared2FCBBoxHeadTask", "ConvFCBBoxHeadTask"):
+    for name in ("FasterRCNNRoIReplay", "StandardMultiPrototypeReplayHead", "StandardPrototypeReplayHead",
+                 "StandardRoIReplayHead", "Shared2FCBBoxHeadTask", "ConvFCBBoxHeadTask"):
         assert r.MODELS.get(name) is not None, name
 
 
@@ -123,6 +124,22 @@ def test_task_head_forward_and_replay_loss_vs_reference_golden(N, golden_dir):
         np.testing.assert_allclose(m.weight.grad.numpy(), g[f"gW_shared{i}"], rtol=1e-4, atol=1e-7)
     losses = h.add_replay_loss(dict(loss_cls=torch.tensor(1.0)))
     assert set(losses) == {"loss_cls", "replay_loss_cls"}
+
+
+def test_select_five_rois_keeps_exactly_five(N):
+    """head:163-199: foreground rows kept, padded with random background / trimmed at random to 5."""
+    from nsgp_repre_amd.roi_heads import select_five_rois
+    bg = 20
+    torch.manual_seed(0)
+    for n_fg, n_bg in ((0, 30), (2, 30), (5, 30), (9, 30), (3, 1), (0, 3)):
+        cls = torch.cat([torch.randint(0, bg, (n_fg,)), torch.full((n_bg,), bg)])[torch.randperm(n_fg + n_bg)]
+        m = select_five_rois(cls.clone(), bg)
+        assert int(m.sum()) == min(5, n_fg + n_bg)
+        fg = cls != bg
+        if n_fg <= 5:
+            assert bool((m | ~fg).all())            # every foreground row survives
+        else:
+            assert bool((~m | fg).all())            # only foreground rows survive
 
 
 def test_detector_mode_dispatch(N):
