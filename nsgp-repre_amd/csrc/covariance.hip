@@ -95,8 +95,8 @@ __global__ __launch_bounds__(256, 2) void nsgp_cov_syrk_kernel(const float* __re
             stage_im2col(xm, base_a, g, l_beg + t * BK, l_end, ra[decltype(s)::value]);
             stage_im2col(xm, base_b, g, l_beg + t * BK, l_end, rb[decltype(s)::value]);
         },
-        [&](float* img, int, auto s) { write_rows_noscale(img, ra[decltype(s)::value]); },
-        [&](float* img, int, auto s) { write_rows_noscale(img, rb[decltype(s)::value]); });
+        [&](float* img, int, auto s) { write_rows(img, ra[decltype(s)::value]); },
+        [&](float* img, int, auto s) { write_rows(img, rb[decltype(s)::value]); });
     float* out = partial + (long)blockIdx.y * g.D * g.D;
 #pragma unroll
     for (int mi = 0; mi < 2; ++mi)

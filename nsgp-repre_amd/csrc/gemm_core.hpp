@@ -11,9 +11,12 @@
 // operand by ds_read_b32.  fp32 MFMA is so slow relative to LDS (4 reads feed
 // 256 MFMA cycles) that LDS bandwidth is irrelevant; the layouts below are
 // chosen only to be bank-conflict free:
-//   "row" image  T[128][33]: 128 rows (m or n) x 32 k, padded to 33 so that
-//       lane (l&31) -> row, (l>>5) -> k reads 32 distinct banks;
-//   "KN" image   T[32][128]: k rows x 128 n, read with n on the lane.
+//   "row" image  T[8][128][4] (+4 floats of padding per k-quad plane): 128 rows (m or n) x 32 k
+//       stored as k-quads, so a staged float4 (4 consecutive k of one row) is ONE ds_write_b128 and
+//       a lane's operand for four consecutive MFMAs is ONE ds_read_b128 (row on the lane, lanes
+//       0-31 take quad q, lanes 32-63 quad q+1: MFMA j then contracts k = 4(q + l>>5) + j on both
+//       operands).  The plane padding spreads the 8 lanes that stage one row's 8 quads over 8 slots;
+//   "KN" image   T[32][128]: k rows x 128 n, read with n on the lane (ds_read_b32).
 #pragma once
 #include <hip/hip_runtime.h>
 
@@ -23,8 +26,8 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 constexpr int BM = 128, BN = 128, BK = 32;
 constexpr int THREADS = 256;
-constexpr int ROW_LD = BK + 1;                       // padded row image
-constexpr int ROW_IMG = BM * ROW_LD;                 // floats
+constexpr int QPLANE = BM * 4 + 4;                   // one k-quad plane of the row image (floats), padded
+constexpr int ROW_IMG = (BK / 4) * QPLANE;           // floats (4128)
 constexpr int KN_IMG = BK * BN;                      // floats
 // LDS carve (floats): [A0][A1][B0][B1]; B images sized for the larger (row) form.
 constexpr int SMEM_FLOATS = 2 * ROW_IMG + 2 * ROW_IMG;
@@ -76,24 +79,14 @@ __device__ __forceinline__ void stage_kn(const float* __restrict__ base, long ld
     for (int j = 0; j < 4; ++j) fetch4<FAST>(base, ld, n_k, n_n, k0 + (t >> 5) + 8 * j, n0 + (t & 31) * 4, r[j]);
 }
 
-__device__ __forceinline__ void write_rows(float* __restrict__ img, const float (&r)[4][4], float scale) {
-    const int t = threadIdx.x;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        float* dst = img + ((t >> 3) + 32 * j) * ROW_LD + (t & 7) * 4;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) dst[e] = scale * r[j][e];
-    }
+__device__ __forceinline__ float* row_slot(float* img, int j) {
+    const int t = threadIdx.x;   // row (t>>3)+32j, k-quad t&7
+    return img + (t & 7) * QPLANE + ((t >> 3) + 32 * j) * 4;
 }
 
-__device__ __forceinline__ void write_rows_noscale(float* __restrict__ img, const float (&r)[4][4]) {
-    const int t = threadIdx.x;
+__device__ __forceinline__ void write_rows(float* __restrict__ img, const float (&r)[4][4]) {
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        float* dst = img + ((t >> 3) + 32 * j) * ROW_LD + (t & 7) * 4;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) dst[e] = r[j][e];
-    }
+    for (int j = 0; j < 4; ++j) *reinterpret_cast<float4*>(row_slot(img, j)) = make_float4(r[j][0], r[j][1], r[j][2], r[j][3]);
 }
 
 __device__ __forceinline__ void write_kn(float* __restrict__ img, const float (&r)[4][4]) {
@@ -105,32 +98,43 @@ __device__ __forceinline__ void write_kn(float* __restrict__ img, const float (&
     }
 }
 
-// ---- one K-step of MFMAs for this wave's 64x64 sub-tile --------------------
-// A operand of v_mfma_f32_32x32x2_f32: lane l holds A[i = l&31][k = l>>5];
-// B operand: lane l holds B[k = l>>5][j = l&31].
+// ---- MFMAs of k in [KK0, KK1) (multiples of 8) for this wave's 64x64 sub-tile -------------------
+// v_mfma_f32_32x32x2_f32: lane l supplies A[i = l&31][k'] and B[k'][j = l&31] with k' chosen by l>>5.
+// Per pair of k-quads (q, q+1): lane half h reads quad q+h of its A row(s) with one ds_read_b128 and
+// MFMA j (j = 0..3) contracts k = 4(q+h) + j.
 template <bool B_ROWS, int KK0 = 0, int KK1 = BK>
 __device__ __forceinline__ void mfma_kstep(const float* __restrict__ As, const float* __restrict__ Bs,
                                            f32x16 (&acc)[2][2], int wm, int wn) {
     const int lane = threadIdx.x & 63;
     const int r = lane & 31, h = lane >> 5;
-    const float* a_base = As + (wm * 64 + r) * ROW_LD + h;
-    const float* b_base = B_ROWS ? (Bs + (wn * 64 + r) * ROW_LD + h) : (Bs + h * BN + wn * 64 + r);
+    const float* a_base = As + h * QPLANE + (wm * 64 + r) * 4;
+    const float* b_rows = Bs + h * QPLANE + (wn * 64 + r) * 4;   // B_ROWS
+    const float* b_kn = Bs + (4 * h) * BN + wn * 64 + r;          // KN
 #pragma unroll
-    for (int kk = KK0; kk < KK1; kk += 2) {
-        const float a0 = a_base[kk];
-        const float a1 = a_base[32 * ROW_LD + kk];
-        float b0, b1;
+    for (int q = KK0 / 4; q < KK1 / 4; q += 2) {
+        const float4 a0 = *reinterpret_cast<const float4*>(a_base + q * QPLANE);
+        const float4 a1 = *reinterpret_cast<const float4*>(a_base + q * QPLANE + 32 * 4);
+        float b0[4], b1[4];
         if (B_ROWS) {
-            b0 = b_base[kk];
-            b1 = b_base[32 * ROW_LD + kk];
+            const float4 x = *reinterpret_cast<const float4*>(b_rows + q * QPLANE);
+            const float4 y = *reinterpret_cast<const float4*>(b_rows + q * QPLANE + 32 * 4);
+            b0[0] = x.x; b0[1] = x.y; b0[2] = x.z; b0[3] = x.w;
+            b1[0] = y.x; b1[1] = y.y; b1[2] = y.z; b1[3] = y.w;
         } else {
-            b0 = b_base[kk * BN];
-            b1 = b_base[kk * BN + 32];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                b0[j] = b_kn[(4 * q + j) * BN];
+                b1[j] = b_kn[(4 * q + j) * BN + 32];
+            }
         }
-        acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
-        acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
-        acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
-        acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+        const float a0v[4] = {a0.x, a0.y, a0.z, a0.w}, a1v[4] = {a1.x, a1.y, a1.z, a1.w};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0v[j], b0[j], acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0v[j], b1[j], acc[0][1], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1v[j], b0[j], acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1v[j], b1[j], acc[1][1], 0, 0, 0);
+        }
     }
 }
 
@@ -150,35 +154,27 @@ __device__ __forceinline__ int acc_row(int reg, int lane) { return (reg & 3) + 8
 // the fly, `F / F.norm(dim=-1, keepdim=True)`) or with k < k_lo zeroed (projector build: the
 // basis is the column range [k_lo, D) of V but loads start at an aligned k).
 __device__ __forceinline__ void write_rows_div(float* __restrict__ img, const float (&r)[4][4], const float (&div)[4]) {
-    const int t = threadIdx.x;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        float* dst = img + ((t >> 3) + 32 * j) * ROW_LD + (t & 7) * 4;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) dst[e] = r[j][e] / div[j];
-    }
+    for (int j = 0; j < 4; ++j)
+        *reinterpret_cast<float4*>(row_slot(img, j)) = make_float4(r[j][0] / div[j], r[j][1] / div[j], r[j][2] / div[j], r[j][3] / div[j]);
 }
 
 __device__ __forceinline__ void write_rows_klo(float* __restrict__ img, const float (&r)[4][4], int k0, int k_lo) {
-    const int t = threadIdx.x;
+    const int k = k0 + (threadIdx.x & 7) * 4;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        float* dst = img + ((t >> 3) + 32 * j) * ROW_LD + (t & 7) * 4;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) dst[e] = (k0 + (t & 7) * 4 + e >= k_lo) ? r[j][e] : 0.0f;
-    }
+    for (int j = 0; j < 4; ++j)
+        *reinterpret_cast<float4*>(row_slot(img, j)) = make_float4(k + 0 >= k_lo ? r[j][0] : 0.0f, k + 1 >= k_lo ? r[j][1] : 0.0f,
+                                                                   k + 2 >= k_lo ? r[j][2] : 0.0f, k + 3 >= k_lo ? r[j][3] : 0.0f);
 }
 
 // k >= k_hi zeroed (low-rank projection: the operands' K extent is the rank r, loads run to the
 // next multiple of 32 inside valid memory)
 __device__ __forceinline__ void write_rows_khi(float* __restrict__ img, const float (&r)[4][4], int k0, int k_hi) {
-    const int t = threadIdx.x;
+    const int k = k0 + (threadIdx.x & 7) * 4;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        float* dst = img + ((t >> 3) + 32 * j) * ROW_LD + (t & 7) * 4;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) dst[e] = (k0 + (t & 7) * 4 + e < k_hi) ? r[j][e] : 0.0f;
-    }
+    for (int j = 0; j < 4; ++j)
+        *reinterpret_cast<float4*>(row_slot(img, j)) = make_float4(k + 0 < k_hi ? r[j][0] : 0.0f, k + 1 < k_hi ? r[j][1] : 0.0f,
+                                                                   k + 2 < k_hi ? r[j][2] : 0.0f, k + 3 < k_hi ? r[j][3] : 0.0f);
 }
 
 // ---- the software pipeline shared by every MFMA kernel ------------------------------------
@@ -247,7 +243,7 @@ __device__ __forceinline__ void mfma_pipeline(int nk, float* smem, f32x16 (&acc)
     if (t < nk) kstep_pipelined<B_ROWS, 0>(smem, acc, wm, wn, last, last, load, write_a, write_b);
 }
 
-// ---- dense tile: acc = (scale*A[m0.., :]) x B ------------------------------------------------
+// ---- dense tile: acc = A[m0.., :] x B (callers apply any scalar factor in their epilogue) ------------------------------------------------
 // A: [M x K] row-major (lda).  B_ROWS=false: B is [K x N] row-major (ldb), n contiguous.
 // B_ROWS=true: B is given as [N x K] row-major (ldb), i.e. acc = A x B^T.
 // (A finer interleave -- 16 slots of 4 MFMAs with one load / LDS-write chunk pinned after each --
@@ -255,7 +251,7 @@ __device__ __forceinline__ void mfma_pipeline(int nk, float* smem, f32x16 (&acc)
 //  stop the compiler from batching LDS reads ahead of the MFMAs.)
 template <bool FAST_A, bool FAST_B, bool B_ROWS>
 __device__ __forceinline__ void gemm_tile(const float* __restrict__ A, long lda, const float* __restrict__ B,
-                                          long ldb, int M, int N, int K, int m0, int n0, float a_scale,
+                                          long ldb, int M, int N, int K, int m0, int n0,
                                           float* smem, f32x16 (&acc)[2][2]) {
     float ra[2][4][4], rb[2][4][4];
     mfma_pipeline<B_ROWS>(
@@ -266,9 +262,9 @@ __device__ __forceinline__ void gemm_tile(const float* __restrict__ A, long lda,
             if (B_ROWS) stage_rows<FAST_B>(B, ldb, N, K, n0, t * BK, rb[S]);
             else stage_kn<FAST_B>(B, ldb, K, N, t * BK, n0, rb[S]);
         },
-        [&](float* img, int, auto s) { write_rows(img, ra[decltype(s)::value], a_scale); },
+        [&](float* img, int, auto s) { write_rows(img, ra[decltype(s)::value]); },
         [&](float* img, int, auto s) {
-            if (B_ROWS) write_rows_noscale(img, rb[decltype(s)::value]);
+            if (B_ROWS) write_rows(img, rb[decltype(s)::value]);
             else write_kn(img, rb[decltype(s)::value]);
         });
 }

@@ -183,7 +183,7 @@ __global__ __launch_bounds__(256) void nsgp_update_kernel(const ChunkDev* __rest
 // ---- launch 2: grouped projection GEMM ---------------------------------------
 template <bool FAST, bool ACCUM>
 __device__ __forceinline__ void store_tile(float* __restrict__ C, long ldc, int M, int N, int m0, int n0,
-                                           const f32x16 (&acc)[2][2]) {
+                                           const f32x16 (&acc)[2][2], float scale) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int wm = wave >> 1, wn = wave & 1;
 #pragma unroll
@@ -196,7 +196,7 @@ __device__ __forceinline__ void store_tile(float* __restrict__ C, long ldc, int 
                 const int row = m0 + wm * 64 + mi * 32 + acc_row(r, lane);
                 if (FAST || (row < M && col < N)) {
                     gfloat* dst = as_global(C) + (long)row * ldc + col;
-                    *dst = ACCUM ? (*dst + acc[mi][ni][r]) : acc[mi][ni][r];
+                    *dst = ACCUM ? (*dst + scale * acc[mi][ni][r]) : scale * acc[mi][ni][r];
                 }
             }
         }
@@ -226,10 +226,12 @@ __global__ __launch_bounds__(256, 2) void nsgp_project_kernel(const TileDev* __r
     // the grad pointer is only known at step time: a misaligned one (e.g. a view into a flat
     // bucket) takes the guarded scalar loader for the A operand only
     if (!FAST || ((uintptr_t)A & 15u) == 0)
-        gemm_tile<FAST, FAST, false>(A, L.cols, L.proj, L.cols, L.rows, L.cols, L.cols, t.m0, t.n0, scale, smem, acc);
+        gemm_tile<FAST, FAST, false>(A, L.cols, L.proj, L.cols, L.rows, L.cols, L.cols, t.m0, t.n0, smem, acc);
     else
-        gemm_tile<false, true, false>(A, L.cols, L.proj, L.cols, L.rows, L.cols, L.cols, t.m0, t.n0, scale, smem, acc);
-    store_tile<FAST, true>(L.p, L.cols, L.rows, L.cols, t.m0, t.n0, acc);  // p.data.add_(update_)  :95
+        gemm_tile<false, true, false>(A, L.cols, L.proj, L.cols, L.rows, L.cols, L.cols, t.m0, t.n0, smem, acc);
+    // p.data.add_(update_) :95 with update_ = (-(lr*S)) @ P; the scalar is applied once per output
+    // element here instead of once per staged operand element (differs by one fp32 rounding per term)
+    store_tile<FAST, true>(L.p, L.cols, L.rows, L.cols, t.m0, t.n0, acc, scale);
 }
 
 template <bool FAST>
@@ -241,9 +243,9 @@ __global__ __launch_bounds__(256, 2) void nsgp_project_single_kernel(const float
     f32x16 acc[2][2];
     zero_acc(acc);
     const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
-    gemm_tile<FAST, FAST, false>(A, cols, P, cols, rows, cols, cols, m0, n0, scale, smem, acc);
-    if (accumulate) store_tile<FAST, true>(out, cols, rows, cols, m0, n0, acc);
-    else store_tile<FAST, false>(out, cols, rows, cols, m0, n0, acc);
+    gemm_tile<FAST, FAST, false>(A, cols, P, cols, rows, cols, cols, m0, n0, smem, acc);
+    if (accumulate) store_tile<FAST, true>(out, cols, rows, cols, m0, n0, acc, scale);
+    else store_tile<FAST, false>(out, cols, rows, cols, m0, n0, acc, scale);
 }
 
 // ---- low-rank form:  p += c * (u - (u U) U^T),  u = scale*S,  U = V[:, :r]  ------------------------
@@ -286,9 +288,9 @@ __global__ __launch_bounds__(256, 2) void nsgp_lowrank_p1_kernel(const TileDev* 
             else stage_rows<false>(A, L.cols, L.rows, L.cols, t.m0, k0 + kt * BK, ra[S]);
             stage_kn<true>(L.basis, L.cols, L.cols, L.cols, k0 + kt * BK, t.n0, rb[S]);
         },
-        [&](float* img, int, auto s) { write_rows(img, ra[decltype(s)::value], scale); },
+        [&](float* img, int, auto s) { write_rows(img, ra[decltype(s)::value]); },
         [&](float* img, int, auto s) { write_kn(img, rb[decltype(s)::value]); });
-    store_tile<true, false>(L.slabs + (long)t.pad * L.rows * L.rpad, L.rpad, L.rows, L.rpad, t.m0, t.n0, acc);
+    store_tile<true, false>(L.slabs + (long)t.pad * L.rows * L.rpad, L.rpad, L.rows, L.rpad, t.m0, t.n0, acc, scale);
 }
 
 __global__ __launch_bounds__(256) void nsgp_lowrank_reduce_kernel(const ChunkDev* __restrict__ chunks,
