@@ -64,8 +64,12 @@ def make_basis(D, dev, seed):
     """A random orthonormal eigenbasis V [D x D]; the synthetic rank of the feature space is r = D//16,
     so the projector is V[:, r:] V[:, r:]^T (built by the HIP SYRK kernel through set_basis)."""
     g = torch.Generator(device=dev).manual_seed(seed)
-    Q, _ = torch.linalg.qr(torch.randn(D, D, device=dev, generator=g))
-    return Q.contiguous(), max(1, D // 16)
+    V = torch.eye(D, device=dev)
+    for _ in range(4):   # a product of 4 Householder reflections: dense, orthonormal to a few ulp, 8 launches
+        u = torch.randn(D, 1, device=dev, generator=g)
+        u = u / u.norm()
+        V = V - 2.0 * (V @ u) @ u.t()
+    return V.contiguous(), max(1, D // 16)
 
 
 class ReplayHead(torch.nn.Module):

@@ -47,7 +47,7 @@ struct LayerDev {
     const float* basis;
     float* T;
     float* slabs;
-    int rank, rpad, nsplit;
+    int rank, rpad, nsplit, kchunk;
     float basis_scale;
 };
 
@@ -55,7 +55,7 @@ struct TileDev {
     int layer, m0, n0, pad;  // pad: split-K slice index (low-rank phase 1)
 };
 
-constexpr int LR_KCHUNK = 512;  // K extent of one low-rank phase-1 tile
+constexpr int LR_KCHUNK_DEFAULT = 512;  // K extent of one low-rank phase-1 tile (the plan may pick another)
 
 struct ChunkDev {
     int tensor;
@@ -274,8 +274,8 @@ __global__ __launch_bounds__(256, 2) void nsgp_lowrank_p1_kernel(const TileDev* 
     const float* A;
     float scale;
     lowrank_source<OPT>(L, dyn, A, scale);
-    const int k0 = t.pad * LR_KCHUNK;
-    const int k1 = min(k0 + LR_KCHUNK, L.cols);
+    const int k0 = t.pad * L.kchunk;
+    const int k1 = min(k0 + L.kchunk, L.cols);
     f32x16 acc[2][2];
     zero_acc(acc);
     float ra[2][4][4], rb[2][4][4];
@@ -393,7 +393,30 @@ static bool tensor_lowrank(const nsgp_tensor_t& t) {
            aligned16(t.basis) && aligned16(t.param) && t.proj;
 }
 static int lr_rpad(int rank) { return (rank + BN - 1) / BN * BN; }
-static int lr_nsplit(int cols) { return (cols + LR_KCHUNK - 1) / LR_KCHUNK; }
+static int lr_nsplit(int cols, int kchunk) { return (cols + kchunk - 1) / kchunk; }
+
+// One K chunk for all low-rank layers of a plan: the candidate whose phase-1 grid makes the fewest,
+// fullest rounds on the 512 workgroup slots (cost model: rounds x (fixed tile overhead + K-steps)).
+static int lr_pick_kchunk(const nsgp_tensor_t* tensors, int n) {
+    static const int cand[] = {256, 384, 512, 768, 1024, 1536, 2304};
+    int best = LR_KCHUNK_DEFAULT;
+    double best_cost = 1e300;
+    for (int kc : cand) {
+        long tiles = 0;
+        int maxsteps = 0;
+        for (int i = 0; i < n; ++i) {
+            const nsgp_tensor_t& t = tensors[i];
+            if (!tensor_lowrank(t)) continue;
+            tiles += (long)(t.rows / BM) * (lr_rpad(t.rank) / BN) * lr_nsplit(t.cols, kc);
+            maxsteps = std::max(maxsteps, std::min(kc, t.cols) / BK);
+        }
+        if (tiles == 0) return LR_KCHUNK_DEFAULT;
+        const double rounds = std::ceil(tiles / 512.0);
+        const double cost = rounds * (3.0 + maxsteps);   // in K-step units; 3 ~ prologue + epilogue of a tile
+        if (cost < best_cost) { best_cost = cost; best = kc; }
+    }
+    return best;
+}
 static size_t pad256(size_t x) { return (x + 255) & ~(size_t)255; }
 
 extern "C" size_t nsgp_plan_workspace_bytes(const nsgp_tensor_t* tensors, int n, int optimizer) {
@@ -403,7 +426,7 @@ extern "C" size_t nsgp_plan_workspace_bytes(const nsgp_tensor_t* tensors, int n,
         const nsgp_tensor_t& t = tensors[i];
         if (!t.proj) continue;
         if (optimizer == NSGP_OPT_ADAM) s += pad256((size_t)t.numel * 4);
-        if (tensor_lowrank(t)) s += pad256((size_t)t.rows * lr_rpad(t.rank) * 4) * (1 + lr_nsplit(t.cols));
+        if (tensor_lowrank(t)) s += pad256((size_t)t.rows * lr_rpad(t.rank) * 4) * (1 + lr_nsplit(t.cols, 256));  // worst case split
     }
     return s;
 }
@@ -423,6 +446,7 @@ extern "C" int nsgp_plan_create(nsgp_plan_t** out, const nsgp_tensor_t* tensors,
     std::vector<char> layer_fast;
     double flops = 0, bytes = 0, lr_flops = 0;
     int n_lowrank = 0;
+    const int lr_kchunk = lr_pick_kchunk(tensors, n);
     size_t ws_off = 0;
     for (int i = 0; i < n; ++i) {
         const nsgp_tensor_t& t = tensors[i];
@@ -439,12 +463,13 @@ extern "C" int nsgp_plan_create(nsgp_plan_t** out, const nsgp_tensor_t* tensors,
                 d.u = reinterpret_cast<float*>(static_cast<char*>(workspace) + ws_off);
                 ws_off += ((size_t)t.numel * 4 + 255) & ~(size_t)255;
             }
-            LayerDev L{t.param, t.state0, d.u, t.proj, i, t.rows, t.cols, t.hyper, nullptr, nullptr, nullptr, 0, 0, 0, 1.0f};
+            LayerDev L{t.param, t.state0, d.u, t.proj, i, t.rows, t.cols, t.hyper, nullptr, nullptr, nullptr, 0, 0, 0, 0, 1.0f};
             if (tensor_lowrank(t)) {
                 L.basis = t.basis;
                 L.rank = t.rank;
                 L.rpad = lr_rpad(t.rank);
-                L.nsplit = lr_nsplit(t.cols);
+                L.kchunk = lr_kchunk;
+                L.nsplit = lr_nsplit(t.cols, lr_kchunk);
                 L.basis_scale = t.basis_scale;
                 const size_t one = pad256((size_t)t.rows * L.rpad * 4);
                 L.T = reinterpret_cast<float*>(static_cast<char*>(workspace) + ws_off);

@@ -16,7 +16,7 @@ OURS = ("nsgp_", "repre_")
 
 
 def short(name):
-    for key in ("nsgp_project_kernel", "nsgp_update_kernel", "nsgp_project_single_kernel", "nsgp_projector_kernel",
+    for key in ("nsgp_lowrank_p1_kernel", "nsgp_lowrank_p2_kernel", "nsgp_lowrank_reduce_kernel", "nsgp_project_kernel", "nsgp_update_kernel", "nsgp_project_single_kernel", "nsgp_projector_kernel",
                 "nsgp_cov_syrk_kernel", "nsgp_cov_reduce_kernel", "nsgp_batch_mean_pad_kernel", "repre_sim_mask_kernel",
                 "repre_row_norm_kernel", "repre_masked_sum_kernel"):
         if key in name:
