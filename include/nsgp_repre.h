@@ -180,6 +180,22 @@ size_t repre_masked_mean_workspace_bytes(int n, int d);
 int repre_masked_mean(const float* feats, int n, int d, const uint64_t* rowmask, int n_selected,
                       float* out, void* workspace, size_t workspace_bytes, void* stream);
 
+/* ------------------------------------------------------------------------
+ * EWC regulariser on the BatchNorm parameters  
+ * Replaces EWCHook.__call__, mmdet/engine/runner/nsrunner_roi_replay.py:1055-1073, which launches
+ * ~5 elementwise/reduction kernels per registered parameter (~106 for R-50) every step:
+ *   loss = weight * sum_n sum_t sum_i F[n][t][i] * (theta[n][i] - theta_old[n][t][i])^2
+ * One launch for the loss (+ a 1-block deterministic finish), one for its gradient
+ *   grad[n][i] = grad_out * 2*weight * sum_t F[n][t][i] * (theta[n][i] - theta_old[n][t][i]).
+ * table: DEVICE array of n_tensors records of 6 int64 each:
+ *   { theta ptr, importance ptr [T x numel], old ptr [T x numel], grad ptr (backward only), numel, T }.
+ * partials: >= n_tensors doubles of device scratch.  loss_out / grad_out_scalar: device fp32 scalars.
+ * ------------------------------------------------------------------------ */
+int nsgp_ewc_loss(const int64_t* table, int n_tensors, float weight, double* partials, float* loss_out,
+                  void* stream);
+int nsgp_ewc_grad(const int64_t* table, int n_tensors, float weight, const float* grad_out_scalar,
+                  void* stream);
+
 #ifdef __cplusplus
 }
 #endif

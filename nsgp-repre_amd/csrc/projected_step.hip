@@ -55,6 +55,7 @@ struct TileDev {
     int layer, m0, n0, pad;  // pad: split-K slice index (low-rank phase 1)
 };
 
+constexpr int LR_REDUCE_CHUNK = 2048;   // elements per workgroup of the slab reduce (many small blocks: T is small)
 constexpr int LR_KCHUNK_DEFAULT = 512;  // K extent of one low-rank phase-1 tile (the plan may pick another)
 
 struct ChunkDev {
@@ -298,7 +299,7 @@ __global__ __launch_bounds__(256) void nsgp_lowrank_reduce_kernel(const ChunkDev
     const ChunkDev c = chunks[blockIdx.x];
     const LayerDev L = layers[c.tensor];
     const long n = (long)L.rows * L.rpad;
-    const long end = (c.start + CHUNK < n) ? c.start + CHUNK : n;
+    const long end = (c.start + LR_REDUCE_CHUNK < n) ? c.start + LR_REDUCE_CHUNK : n;
     for (long i = c.start + (long)threadIdx.x * 4; i < end; i += 256 * 4) {   // rpad % 128 == 0 -> n % 4 == 0
         f32x4 s = *(const gf32x4*)(L.slabs + i);
         for (int k = 1; k < L.nsplit; ++k) s += *(const gf32x4*)(L.slabs + (long)k * n + i);
@@ -398,7 +399,7 @@ static int lr_nsplit(int cols, int kchunk) { return (cols + kchunk - 1) / kchunk
 // One K chunk for all low-rank layers of a plan: the candidate whose phase-1 grid makes the fewest,
 // fullest rounds on the 512 workgroup slots (cost model: rounds x (fixed tile overhead + K-steps)).
 static int lr_pick_kchunk(const nsgp_tensor_t* tensors, int n) {
-    static const int cand[] = {256, 384, 512, 768, 1024, 1536, 2304};
+    static const int cand[] = {512, 768, 1024, 1536};   // >= 512: every extra slab is re-read by the reduce
     int best = LR_KCHUNK_DEFAULT;
     double best_cost = 1e300;
     for (int kc : cand) {
@@ -561,7 +562,7 @@ extern "C" int nsgp_plan_create(nsgp_plan_t** out, const nsgp_tensor_t* tensors,
                     for (int m = 0; m < L.rows / BM; ++m) lr1.push_back(TileDev{li, m * BM, j * BN, ks});
             for (int j = 0; j < L.cols / BN; ++j)
                 for (int m = 0; m < L.rows / BM; ++m) lr2.push_back(TileDev{li, m * BM, j * BN, 0});
-            for (long st = 0; st < (long)L.rows * L.rpad; st += CHUNK) lr_chunks.push_back(ChunkDev{li, 0, st});
+            for (long st = 0; st < (long)L.rows * L.rpad; st += LR_REDUCE_CHUNK) lr_chunks.push_back(ChunkDev{li, 0, st});
         }
     }
     std::vector<TileDev> all_tiles(fast_tiles);

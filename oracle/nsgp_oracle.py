@@ -428,6 +428,31 @@ def replay_loss_from_scores(cls_score: torch.Tensor, labels: torch.Tensor, pre_i
 
 
 # ----------------------------------------------------------------------------
+# 8f-1: EWC regulariser on the BatchNorm parameters
+# ----------------------------------------------------------------------------
+
+
+def ewc_registered(names: Sequence[str]) -> List[str]:
+    """runner:1010-1031 ``register_params``: names containing "bn" and not "teacher_model"."""
+    return [n for n in names if ("bn" in n) and ("teacher_model" not in n)]
+
+
+def ewc_loss(params: Dict[str, torch.Tensor], importance: Dict[str, List[torch.Tensor]],
+             task_param: Dict[str, List[torch.Tensor]], weight: float = 1000.0) -> torch.Tensor:
+    """runner:1055-1073 ``EWCHook.__call__``: sum_n weight * sum((cat(F_n) * (theta_n - cat(theta*_n))**2))
+    over parameters that require grad, accumulated in that order."""
+    total = 0
+    for n, p in params.items():
+        if not p.requires_grad:
+            continue
+        F_ = torch.cat(importance[n], dim=0)
+        old = torch.cat(task_param[n], dim=0)
+        new = p.unsqueeze(0).expand(old.shape)
+        total = total + weight * (F_ * (new - old) ** 2).sum()
+    return total
+
+
+# ----------------------------------------------------------------------------
 # C1 / C2 collectives, stated as plain list-of-ranks arithmetic
 # ----------------------------------------------------------------------------
 

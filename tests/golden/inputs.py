@@ -180,3 +180,23 @@ def g5_bank(k=14):
     bank = np.maximum(rng.standard_normal((k, G5_IN)), 0).astype(np.float32)
     labels = rng.integers(0, G5_TASK_SPLIT[G5_TASK_ID - 1], size=k).astype(np.int64)
     return bank, labels
+
+
+# ------------------------------------------------------------------ G6 (EWC regulariser)
+G6_SHAPES = [("backbone.layer1.0.bn1.weight", (64,)), ("backbone.layer1.0.bn1.bias", (64,)),
+             ("backbone.layer3.2.bn3.weight", (1031,)), ("backbone.layer4.0.bn2.bias", (512,)),
+             ("backbone.bn1.weight", (7,)), ("teacher_model.backbone.bn1.weight", (7,)), ("neck.conv.weight", (4, 3, 1, 1))]
+G6_TASKS = 2
+
+
+def g6_tensors():
+    """name -> (theta, [importance_t], [task_param_t]) ; only names with 'bn' and without
+    'teacher_model' are regularised (runner:1010-1031)."""
+    out = {}
+    for i, (n, shp) in enumerate(G6_SHAPES):
+        rng = np.random.default_rng(600 + i)
+        theta = rng.standard_normal(shp).astype(np.float32)
+        imp = [np.abs(rng.standard_normal((1,) + shp)).astype(np.float32) * 1e-2 for _ in range(G6_TASKS)]
+        old = [(theta[None] + 0.1 * rng.standard_normal((1,) + shp)).astype(np.float32) for _ in range(G6_TASKS)]
+        out[n] = (theta, imp, old)
+    return out

@@ -211,6 +211,36 @@ def run_replay_loss():
     save("g5_replay_loss.npz", **out)
 
 
+# ---------------------------------------------------------------- G6 EWC regulariser
+def run_ewc():
+    Runner = ref_runner.BRNullSpaceRunner
+    tensors = I.g6_tensors()
+    model = nn.Module()
+    plist = {}
+    for n, (theta, imp, old) in tensors.items():
+        p = nn.Parameter(torch.from_numpy(theta.copy()))
+        model.register_parameter(n.replace(".", "__"), p)
+        plist[n] = p
+    # named_parameters() must yield the dotted names: a tiny shim
+    model.named_parameters = lambda *a, **k: iter(plist.items())
+    fake = object.__new__(Runner)
+    fake.model = model
+    fake.register_params()                                   # runner:1010-1031
+    reg_names = sorted(fake.reg_params.keys())
+    terms = {"importance": {n: [torch.from_numpy(a) for a in tensors[n][1]] for n in reg_names},
+             "task_param": {n: [torch.from_numpy(a) for a in tensors[n][2]] for n in reg_names}}
+    holder = type("M", (), {})()
+    holder.loss = lambda *a, **k: {"loss_cls": torch.tensor(1.0)}
+    hook = ref_runner.EWCHook(module=holder, reg_params=fake.reg_params, ewc_reg_terms=terms)
+    res = hook()
+    res["ewc_loss"].backward()
+    out = {"ewc_loss": res["ewc_loss"].detach().numpy(), "n_reg": np.int64(len(reg_names))}
+    for k, n in enumerate(reg_names):
+        out[f"name_{k}"] = np.array(n)
+        out[f"grad_{k}"] = fake.reg_params[n].grad.numpy()
+    save("g6_ewc.npz", **out)
+
+
 if __name__ == "__main__":
     for kind in ("sgd", "sgd_nesterov", "adamw", "adamw_amsgrad", "adam", "sgdna"):
         run_optimizer(kind)
@@ -218,3 +248,4 @@ if __name__ == "__main__":
     run_covariance()
     run_prototypes()
     run_replay_loss()
+    run_ewc()

@@ -163,3 +163,55 @@ def test_two_task_run_keeps_old_features_fixed(N, dev):
         assert dW.norm() > 0
         # task 2's own covariance file = task 1's + the new pass (checked in the cal_fea_in test)
         assert os.path.exists(os.path.join(w2, "covariance.pth"))
+
+
+def test_ewc_regulariser_vs_reference_golden(N, dev, golden_dir):
+    """fused multi-tensor EWC loss + gradient vs the reference's EWCHook output (G6)."""
+    g = np.load(os.path.join(golden_dir, "g6_ewc.npz"))
+    tensors = I.g6_tensors()
+
+    class M(nn.Module):
+        pass
+    model = M()
+    named = {}
+    for n, (theta, _, _) in tensors.items():
+        named[n] = nn.Parameter(torch.from_numpy(theta.copy()).to(dev))
+    model.named_parameters = lambda *a, **k: iter(named.items())
+    reg_params = N.runner.ewc.register_params(model)
+    assert sorted(reg_params) == sorted(str(g[f"name_{k}"]) for k in range(int(g["n_reg"])))
+    terms = {"importance": {n: [torch.from_numpy(a) for a in tensors[n][1]] for n in reg_params},
+             "task_param": {n: [torch.from_numpy(a) for a in tensors[n][2]] for n in reg_params}}
+    holder = type("H", (), {})()
+    holder.loss = lambda *a, **k: {"loss_cls": torch.ones((), device=dev)}
+    hook = N.runner.ewc.EWCHook(holder, reg_params, terms)
+    res = hook()
+    assert set(res) == {"loss_cls", "ewc_loss"}
+    np.testing.assert_allclose(res["ewc_loss"].item(), g["ewc_loss"], rtol=1e-5)
+    (res["ewc_loss"] * 0.5 + res["loss_cls"]).backward()          # grad_out = 0.5 reaches the kernel
+    for k in range(int(g["n_reg"])):
+        n = str(g[f"name_{k}"])
+        assert _rel(reg_params[n].grad, 0.5 * torch.from_numpy(g[f"grad_{k}"])) <= 1e-5, n
+    # frozen parameters drop out, exactly like `if not p.requires_grad: continue`
+    for p in reg_params.values():
+        p.requires_grad_(False)
+    assert N.runner.ewc.EWCRegulariser(reg_params, terms).n == 0
+
+
+def test_ewc_importance_accumulation_and_file(N, dev):
+    """calculate_save_importance (runner:946-990) restated: F += grad^2 * len(batch)/len(loader); file layout."""
+    p = {"backbone.bn1.weight": nn.Parameter(torch.randn(9, device=dev)), "backbone.bn1.bias": nn.Parameter(torch.randn(9, device=dev))}
+    imp = {n: torch.zeros_like(v) for n, v in p.items()}
+    ref = {n: torch.zeros(9) for n in p}
+    for b in range(3):
+        for n, v in p.items():
+            v.grad = torch.randn(9, device=dev)
+            ref[n] += v.grad.cpu() ** 2 * 2 / 3
+        N.runner.ewc.accumulate_importance(imp, p, batch_len=2, loader_len=3)
+    for n in p:
+        assert _rel(imp[n], ref[n]) <= 1e-6
+    with tempfile.TemporaryDirectory() as td:
+        terms = N.runner.ewc.save_importance(td, {}, imp, p)
+        loaded = N.runner.ewc.load_importance(os.path.join(td, "ewc_reg_terms_ewc.pth"), dev)
+        assert set(loaded) == {"importance", "task_param"} and loaded["importance"]["backbone.bn1.bias"][0].shape == (1, 9)
+        terms = N.runner.ewc.save_importance(td, loaded, imp, p)
+        assert len(terms["task_param"]["backbone.bn1.weight"]) == 2

@@ -170,3 +170,19 @@ def test_layer_table_sums():
     L = O.resnet_fpn_projected_layers(101)
     assert len(L) == 101
     assert abs(sum(2 * c * d * d for _, c, d in L) / 1e9 - 175.9) < 0.05
+
+
+def test_g6_ewc_regulariser(golden_dir):
+    """EWCHook (runner:1038-1073) through the reference vs the oracle restatement."""
+    g = _load(golden_dir, "g6_ewc.npz")
+    tensors = I.g6_tensors()
+    reg = O.ewc_registered(list(tensors))
+    assert sorted(reg) == sorted(str(g[f"name_{k}"]) for k in range(int(g["n_reg"])))
+    params = {n: torch.from_numpy(tensors[n][0].copy()).requires_grad_(True) for n in sorted(reg)}
+    imp = {n: [torch.from_numpy(a) for a in tensors[n][1]] for n in reg}
+    old = {n: [torch.from_numpy(a) for a in tensors[n][2]] for n in reg}
+    loss = O.ewc_loss(params, imp, old)
+    np.testing.assert_allclose(loss.item(), g["ewc_loss"], rtol=1e-6)
+    loss.backward()
+    for k in range(int(g["n_reg"])):
+        np.testing.assert_allclose(params[str(g[f"name_{k}"])].grad.numpy(), g[f"grad_{k}"], rtol=1e-5, atol=1e-7)

@@ -64,3 +64,24 @@ for n in (300, 1500, 6000):
     ms = timeit(lambda: ops.sim_counts(F, 0.6), reps=3)
     mm = timeit(lambda: ops.masked_mean(F), reps=3)
     print(f"N={n}: sim_counts {ms:9.3f} ms  {2.0 * n * n * 12544 / ms / 1e9:7.1f} TF (reference FLOPs 2N^2D)   all-row mean {mm:7.3f} ms  {4.0 * n * 12544 / mm / 1e6:7.1f} GB/s", flush=True)
+
+print("== EWC regulariser (R-50: 106 BN tensors, T=1), fused vs the reference's per-parameter loop", flush=True)
+import sys as _s
+_s.path.insert(0, os.path.join(ROOT, "oracle"))
+import nsgp_oracle as O
+sizes = [64] * 8 + [256] * 6 + [128] * 10 + [512] * 10 + [256] * 16 + [1024] * 14 + [512] * 8 + [2048] * 6
+sizes = (sizes + sizes)[:106]
+params = {f"backbone.l{i}.bn.weight": torch.nn.Parameter(torch.randn(n, device=dev)) for i, n in enumerate(sizes)}
+terms = {"importance": {n: [torch.rand(1, p.numel(), device=dev)] for n, p in params.items()},
+         "task_param": {n: [torch.randn(1, p.numel(), device=dev)] for n, p in params.items()}}
+reg = N.runner.ewc.EWCRegulariser(params, terms)
+def fused():
+    for p in params.values(): p.grad = None
+    reg().backward()
+def loop():
+    for p in params.values(): p.grad = None
+    O.ewc_loss(params, terms["importance"], terms["task_param"]).backward()
+tf, tl = timeit(fused, reps=10), timeit(loop, reps=10)
+t0 = time.perf_counter(); [fused() for _ in range(20)]; torch.cuda.synchronize(); wf = (time.perf_counter() - t0) / 20 * 1e3
+t0 = time.perf_counter(); [loop() for _ in range(20)]; torch.cuda.synchronize(); wl = (time.perf_counter() - t0) / 20 * 1e3
+print(f"fused: {tf:.3f} ms GPU / {wf:.3f} ms wall    per-parameter torch loop (the reference's route on this GPU): {tl:.3f} ms GPU / {wl:.3f} ms wall", flush=True)
