@@ -197,11 +197,15 @@ def main():
     for p, o in zip(params, offs):
         p.grad = flat_grads[o:o + p.numel()].view_as(p)
 
+    host_step = []
+
     def one_step():
         flat_grads.copy_(synth_flat)           # the detector's backward() writes the grads (synthetic)
         loss = head(bank, labels, 15)          # RePRE replay loss: forward
         loss.backward()                        # + backward: accumulates into the head's grad views
+        h0 = time.perf_counter()
         opt.step()                             # NSGP projected step: 2 HIP launches
+        host_step.append(time.perf_counter() - h0)
 
     for _ in range(args.warmup):
         one_step()
@@ -248,6 +252,7 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms_per_step,
             "nsgp_step_ms": nsgp_ms,
+            "host_ms_in_optimizer_step": 1e3 * sum(host_step[-args.steps:]) / max(1, len(host_step[-args.steps:])),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": "R-50-FPN VOC 15+5 task 2 (configs[1]): SGDNSCL step over 50 projected layers "

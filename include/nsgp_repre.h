@@ -196,6 +196,18 @@ int nsgp_ewc_loss(const int64_t* table, int n_tensors, float weight, double* par
 int nsgp_ewc_grad(const int64_t* table, int n_tensors, float weight, const float* grad_out_scalar,
                   void* stream);
 
+/* ------------------------------------------------------------------------
+ * Teacher pseudo-label filter  
+ * Replaces the per-box Python loop (one host sync per box) of FasterRCNNRoIReplay.loss,
+ * mmdet/models/detectors/faster_rcnn_roi_replay.py:78-108, for ONE image: boxes [P x 4] xyxy in the
+ * teacher's output order, scores [P], gt_boxes [G x 4].  Box k is dropped if its max IoU with the ground
+ * truth AND with the earlier boxes already accepted into the RoI set exceeds iou_thr (0.7); otherwise
+ * add_rpn[k] = score > rpn_thr, add_roi[k] = score > roi_thr.  P <= 2048.
+ * ------------------------------------------------------------------------ */
+int repre_pseudo_label_filter(const float* boxes, const float* scores, int n_boxes, const float* gt_boxes,
+                              int n_gt, float iou_thr, float rpn_thr, float roi_thr,
+                              unsigned char* add_rpn, unsigned char* add_roi, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

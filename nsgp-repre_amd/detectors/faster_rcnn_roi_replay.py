@@ -19,6 +19,15 @@ except Exception:
     _HAVE_MMDET = False
 
 
+def filter_pseudo_labels(pred_bboxes, pred_scores, gt_bboxes, rpn_thresh: float, roi_thresh: float):
+    """The teacher pseudo-label filter of one image (det:78-108) as ONE kernel instead of a Python loop
+    with a host sync per box: returns (add_to_rpn, add_to_roi) bool masks over the teacher's predictions,
+    in order, so ``gt.cat([gt, pseudo[mask]])`` reproduces the reference's appended sets."""
+    from .. import ops
+    return ops.pseudo_label_filter(pred_bboxes.float().contiguous(), pred_scores.float().contiguous(),
+                                   gt_bboxes.float().contiguous(), rpn_thresh, roi_thresh)
+
+
 class RoIReplayModes:
     """``forward(inputs, data_samples, mode)`` with the two extra modes of det:229-232."""
 
@@ -52,6 +61,27 @@ class FasterRCNNRoIReplay(RoIReplayModes, _Base):
             for k, v in kwargs.items():      # stand-alone: sub-modules are passed in ready-built
                 setattr(self, k, v)
         self.rpn_thresh, self.roi_thresh = 0.5, 0.5   # set by the runner from rr_thresh (runner:439-440)
+
+    def pseudo_labelled_samples(self, batch_inputs, batch_data_samples):  # pragma: no cover - needs mmdet structures
+        """det:65-109: teacher predictions -> (rpn_data_samples, batch_data_samples) with the accepted
+        pseudo boxes appended; the per-box loop is the fused filter above."""
+        import copy
+        import torch
+        with torch.no_grad():
+            self.teacher_model.eval()
+            preds = self.teacher_model.predict(batch_inputs, copy.deepcopy(batch_data_samples), rescale=False)
+            rpn_samples = copy.deepcopy(batch_data_samples)
+            for pred, gt_sample, rpn_sample in zip(preds, batch_data_samples, rpn_samples):
+                inst = pred.pred_instances
+                if len(inst) == 0:
+                    continue
+                to_rpn, to_roi = filter_pseudo_labels(inst.bboxes, inst.scores, gt_sample.gt_instances.bboxes,
+                                                      self.rpn_thresh, self.roi_thresh)
+                pseudo = inst[:]
+                pseudo.__delattr__("scores")
+                rpn_sample.gt_instances = rpn_sample.gt_instances.cat([rpn_sample.gt_instances, pseudo[to_rpn]])
+                gt_sample.gt_instances = gt_sample.gt_instances.cat([gt_sample.gt_instances, pseudo[to_roi]])
+        return rpn_samples, batch_data_samples
 
     def loss(self, batch_inputs, batch_data_samples, use_teacher_student=True):
         if not _HAVE_MMDET:

@@ -143,6 +143,23 @@ def masked_mean(feats: torch.Tensor, rowmask_words: torch.Tensor = None, n_selec
     return out
 
 
+def pseudo_label_filter(boxes: torch.Tensor, scores: torch.Tensor, gt_boxes: torch.Tensor, rpn_thresh: float,
+                        roi_thresh: float, iou_thresh: float = 0.7):
+    """Sequential teacher pseudo-label filter of one image -> (add_to_rpn bool[P], add_to_roi bool[P]) --
+    mmdet/models/detectors/faster_rcnn_roi_replay.py:78-108."""
+    lib = _lib.load_library()
+    P, G = boxes.shape[0], gt_boxes.shape[0]
+    add_rpn = torch.zeros(P, dtype=torch.uint8, device=boxes.device)
+    add_roi = torch.zeros(P, dtype=torch.uint8, device=boxes.device)
+    if P == 0:
+        return add_rpn.bool(), add_roi.bool()
+    gptr = _dev(gt_boxes, "gt_boxes") if G > 0 else C.c_void_p(0)
+    _lib.check(lib.repre_pseudo_label_filter(_dev(boxes, "boxes"), _dev(scores, "scores"), P, gptr, G, float(iou_thresh),
+                                             float(rpn_thresh), float(roi_thresh), _dev(add_rpn, "add_rpn", torch.uint8),
+                                             _dev(add_roi, "add_roi", torch.uint8), _stream()), "repre_pseudo_label_filter")
+    return add_rpn.bool(), add_roi.bool()
+
+
 def unpack_bitmask_row(words: torch.Tensor, n: int) -> torch.Tensor:
     """int64 words (little-endian bit order) -> bool[n] (host-side glue for mask.pth)."""
     w = words.cpu().numpy().view("uint64")

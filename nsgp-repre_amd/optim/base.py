@@ -225,51 +225,68 @@ class NSCLOptimizerBase(Optimizer):
             n_, u_, g_ = max(n_, n.value), u_ + u.value, g_ + g.value
         return n_, u_, g_
 
+    def _validate(self, n, p, group):
+        if p.grad is None:  # the reference dereferences p.grad.data unconditionally (:75)
+            raise AttributeError(f"{n}: 'NoneType' object has no attribute 'data' (parameter has no grad)")
+        if p.grad.is_sparse:
+            raise RuntimeError("Adam does not support sparse gradients, please consider SparseAdam instead")
+        if not p.is_cuda:
+            raise RuntimeError(f"{n}: nsgp_repre_amd optimizers run on the GPU only (no CPU fallback)")
+        if p.dtype != torch.float32 or p.grad.dtype != torch.float32:
+            raise TypeError(f"{n}: parameters and gradients must be fp32")
+        if not p.is_contiguous() or not p.grad.is_contiguous():
+            raise RuntimeError(f"{n}: parameter/gradient must be contiguous")
+
     @torch.no_grad()
     def step(self, closure=None):
-        """One optimization step (SGD_NSCL.py:59-96 semantics, every listed (name, p) pair)."""
+        """One optimization step (SGD_NSCL.py:59-96 semantics, every listed (name, p) pair).
+
+        Host side per step: one pass to fingerprint the (name, parameter, projector) structure, and
+        -- while it is unchanged -- only the gradient pointers and the per-group scalars are refreshed
+        before the single ``nsgp_plan_step`` call per plan."""
         loss = None
         if closure is not None:
             with torch.enable_grad():
                 loss = closure()
         lib = _lib.load_library()
-        entries, key = [], []
+        transforms = self.transforms
+        key = [bool(self.low_rank)]
         for gi, group in enumerate(self.param_groups):
+            svd = group["svd"]
             for n, p in zip(group["names"], group["params"]):
-                if p.grad is None:  # the reference dereferences p.grad.data unconditionally (:75)
-                    raise AttributeError(f"{n}: 'NoneType' object has no attribute 'data' (parameter has no grad)")
-                if p.grad.is_sparse:
-                    raise RuntimeError("Adam does not support sparse gradients, please consider SparseAdam instead")
-                if not p.is_cuda:
-                    raise RuntimeError(f"{n}: nsgp_repre_amd optimizers run on the GPU only (no CPU fallback)")
-                if p.dtype != torch.float32 or p.grad.dtype != torch.float32:
-                    raise TypeError(f"{n}: parameters and gradients must be fp32")
-                if not p.is_contiguous() or not p.grad.is_contiguous():
-                    raise RuntimeError(f"{n}: parameter/gradient must be contiguous")
-                state = self.state[p]
-                if len(state) == 0:
-                    self._init_state(p, state, group)
-                state["step"] += 1
-                entries.append((gi, n, p, state))
-                P = self.transforms.get(n) if n in self.transforms.keys() else None
-                key.append((p.data_ptr(), gi, P.data_ptr() if isinstance(P, torch.Tensor) else 0, bool(group["svd"])))
-        if not entries:
+                P = transforms.get(n) if (svd and n in transforms) else None
+                key.append((p.data_ptr(), gi, P.data_ptr() if isinstance(P, torch.Tensor) else 0))
+        if len(key) == 1:
             return loss
-        key = (tuple(key), bool(self.low_rank))
+        key = tuple(key)
         if key != self._plan_key:
+            entries = []
+            for gi, group in enumerate(self.param_groups):
+                for n, p in zip(group["names"], group["params"]):
+                    self._validate(n, p, group)
+                    state = self.state[p]
+                    if len(state) == 0:
+                        self._init_state(p, state, group)
+                    entries.append((gi, n, p, state))
             self._build_plans(entries)
             self._plan_key = key
         stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+        mutate = int(self.mutate_grad)
         for plan in self._plans:
-            steps = defaultdict(set)
+            grads = plan["grads"]
+            step_of = {}
             for i, (gi, n, p, st) in enumerate(plan["entries"]):
-                plan["grads"][i] = p.grad.data_ptr()
-                steps[gi].add(st["step"])
-            for k, gi in enumerate(plan["groups"]):
-                if len(steps[gi]) != 1:
+                g = p.grad
+                if g is None:
+                    raise AttributeError(f"{n}: 'NoneType' object has no attribute 'data' (parameter has no grad)")
+                grads[i] = g.data_ptr()
+                t = st["step"] + 1
+                st["step"] = t
+                if step_of.setdefault(gi, t) != t:
                     raise RuntimeError("parameters of one param group carry different step counts")
-                self._fill_hyper(plan["hyper"][k], self.param_groups[gi], next(iter(steps[gi])))
-                plan["hyper"][k].write_grad = int(self.mutate_grad)
-            _lib.check(lib.nsgp_plan_step(plan["handle"], plan["grads"], plan["hyper"], len(plan["groups"]), stream),
-                       "nsgp_plan_step")
+            hyper = plan["hyper"]
+            for k, gi in enumerate(plan["groups"]):
+                self._fill_hyper(hyper[k], self.param_groups[gi], step_of[gi])
+                hyper[k].write_grad = mutate
+            _lib.check(lib.nsgp_plan_step(plan["handle"], grads, hyper, len(plan["groups"]), stream), "nsgp_plan_step")
         return loss

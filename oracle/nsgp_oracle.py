@@ -453,6 +453,43 @@ def ewc_loss(params: Dict[str, torch.Tensor], importance: Dict[str, List[torch.T
 
 
 # ----------------------------------------------------------------------------
+# 8f-2: teacher pseudo-label filter  -- PARITY UNPINNED: the reference calls torchvision.ops.box_iou
+# and mmengine's InstanceData, both absent here, so no golden could be produced; this restates the
+# loop of faster_rcnn_roi_replay.py:78-108 with torchvision's published box_iou formula.
+# ----------------------------------------------------------------------------
+
+
+def box_iou(a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
+    """torchvision.ops.box_iou: xyxy boxes, inter / (area_a + area_b - inter), no +1."""
+    area_a = (a[:, 2] - a[:, 0]) * (a[:, 3] - a[:, 1])
+    area_b = (b[:, 2] - b[:, 0]) * (b[:, 3] - b[:, 1])
+    lt = torch.max(a[:, None, :2], b[None, :, :2])
+    rb = torch.min(a[:, None, 2:], b[None, :, 2:])
+    wh = (rb - lt).clamp(min=0)
+    inter = wh[..., 0] * wh[..., 1]
+    return inter / (area_a[:, None] + area_b[None, :] - inter)
+
+
+def pseudo_label_filter(boxes: torch.Tensor, scores: torch.Tensor, gt: torch.Tensor, rpn_thresh: float,
+                        roi_thresh: float, iou_thresh: float = 0.7):
+    """faster_rcnn_roi_replay.py:78-108 for one image: the RoI-side ground truth GROWS inside the loop,
+    so box k is also tested against earlier accepted pseudo boxes."""
+    add_rpn = torch.zeros(len(boxes), dtype=torch.bool)
+    add_roi = torch.zeros(len(boxes), dtype=torch.bool)
+    cur = gt.clone()
+    for k in range(len(boxes)):
+        max_iou = box_iou(boxes[k:k + 1], cur).max().item() if len(cur) > 0 else 0.0
+        if max_iou > iou_thresh:
+            continue
+        if scores[k] > rpn_thresh:
+            add_rpn[k] = True
+        if scores[k] > roi_thresh:
+            add_roi[k] = True
+            cur = torch.cat([cur, boxes[k:k + 1]])
+    return add_rpn, add_roi
+
+
+# ----------------------------------------------------------------------------
 # C1 / C2 collectives, stated as plain list-of-ranks arithmetic
 # ----------------------------------------------------------------------------
 

@@ -215,3 +215,30 @@ def test_ewc_importance_accumulation_and_file(N, dev):
         assert set(loaded) == {"importance", "task_param"} and loaded["importance"]["backbone.bn1.bias"][0].shape == (1, 9)
         terms = N.runner.ewc.save_importance(td, loaded, imp, p)
         assert len(terms["task_param"]["backbone.bn1.weight"]) == 2
+
+
+def test_pseudo_label_filter_vs_oracle(N, dev):
+    """SURVEY 8f-2 (parity unpinned: torchvision/mmengine absent, no golden): the fused sequential
+    filter vs the oracle's restatement of det:78-108 -- bit-exact masks, including the case where a box
+    is rejected only because of an EARLIER accepted pseudo box, empty ground truth and empty predictions."""
+    rng = np.random.default_rng(0)
+    for P, G in ((100, 6), (37, 0), (0, 4), (300, 20), (5, 1)):
+        ctr = rng.uniform(50, 750, size=(max(P, 1), 2))
+        wh = rng.uniform(20, 200, size=(max(P, 1), 2))
+        boxes = np.concatenate([ctr - wh / 2, ctr + wh / 2], axis=1).astype(np.float32)[:P]
+        if P > 10:                       # near-duplicates of earlier boxes: rejected through the grown RoI set
+            boxes[5] = boxes[2] + 1.0
+            boxes[9] = boxes[2] - 0.5
+        scores = np.sort(rng.uniform(0.05, 1.0, size=P).astype(np.float32))[::-1].copy()
+        gctr = rng.uniform(100, 700, size=(G, 2)); gwh = rng.uniform(30, 250, size=(G, 2))
+        gt = np.concatenate([gctr - gwh / 2, gctr + gwh / 2], axis=1).astype(np.float32)
+        if G > 0 and P > 3:
+            boxes[1] = gt[0] + 0.25      # overlaps a real ground-truth box: dropped
+        b, s, g_ = torch.from_numpy(boxes).reshape(-1, 4), torch.from_numpy(scores), torch.from_numpy(gt).reshape(-1, 4)
+        ref_rpn, ref_roi = O.pseudo_label_filter(b, s, g_, 0.5, 0.7)
+        rpn, roi = N.detectors.filter_pseudo_labels(b.to(dev), s.to(dev), g_.to(dev), 0.5, 0.7)
+        assert torch.equal(rpn.cpu(), ref_rpn) and torch.equal(roi.cpu(), ref_roi), (P, G)
+        if P > 10:
+            if ref_roi[2]:
+                assert not ref_roi[5] and not ref_roi[9]    # the sequential dependency is exercised
+            assert bool((ref_roi <= ref_rpn).all())          # roi_thresh >= rpn_thresh
