@@ -243,6 +243,26 @@ __device__ __forceinline__ void mfma_pipeline(int nk, float* smem, f32x16 (&acc)
     if (t < nk) kstep_pipelined<B_ROWS, 0>(smem, acc, wm, wn, last, last, load, write_a, write_b);
 }
 
+// Per-thread base pointers of the four float4 slots a thread stages per operand (FAST path):
+// hoists the 64-bit row*ld products out of the K loop; inside it a load address is base + k offset.
+__device__ __forceinline__ void row_bases(const float* base, long ld, int row0, const float* (&ptr)[4]) {
+    const int t = threadIdx.x;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) ptr[j] = base + (long)(row0 + (t >> 3) + 32 * j) * ld + (t & 7) * 4;
+}
+__device__ __forceinline__ void kn_bases(const float* base, long ld, int n0, const float* (&ptr)[4]) {
+    const int t = threadIdx.x;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) ptr[j] = base + (long)((t >> 5) + 8 * j) * ld + n0 + (t & 31) * 4;
+}
+__device__ __forceinline__ void load4(const float* const (&ptr)[4], long off, float (&r)[4][4]) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const f32x4 q = *(const gf32x4*)(ptr[j] + off);
+        r[j][0] = q[0]; r[j][1] = q[1]; r[j][2] = q[2]; r[j][3] = q[3];
+    }
+}
+
 // ---- dense tile: acc = A[m0.., :] x B (callers apply any scalar factor in their epilogue) ------------------------------------------------
 // A: [M x K] row-major (lda).  B_ROWS=false: B is [K x N] row-major (ldb), n contiguous.
 // B_ROWS=true: B is given as [N x K] row-major (ldb), i.e. acc = A x B^T.
@@ -254,13 +274,22 @@ __device__ __forceinline__ void gemm_tile(const float* __restrict__ A, long lda,
                                           long ldb, int M, int N, int K, int m0, int n0,
                                           float* smem, f32x16 (&acc)[2][2]) {
     float ra[2][4][4], rb[2][4][4];
+    const float *pa[4], *pb[4];
+    if (FAST_A) row_bases(A, lda, m0, pa);
+    if (FAST_B) {
+        if (B_ROWS) row_bases(B, ldb, n0, pb);
+        else kn_bases(B, ldb, n0, pb);
+    }
+    const long bstep = B_ROWS ? (long)BK : (long)BK * ldb;
     mfma_pipeline<B_ROWS>(
         (K + BK - 1) / BK, smem, acc,
         [&](int t, auto s) {
             constexpr int S = decltype(s)::value;
-            stage_rows<FAST_A>(A, lda, M, K, m0, t * BK, ra[S]);
-            if (B_ROWS) stage_rows<FAST_B>(B, ldb, N, K, n0, t * BK, rb[S]);
-            else stage_kn<FAST_B>(B, ldb, K, N, t * BK, n0, rb[S]);
+            if (FAST_A) load4(pa, (long)t * BK, ra[S]);
+            else stage_rows<false>(A, lda, M, K, m0, t * BK, ra[S]);
+            if (FAST_B) load4(pb, t * bstep, rb[S]);
+            else if (B_ROWS) stage_rows<false>(B, ldb, N, K, n0, t * BK, rb[S]);
+            else stage_kn<false>(B, ldb, K, N, t * BK, n0, rb[S]);
         },
         [&](float* img, int, auto s) { write_rows(img, ra[decltype(s)::value]); },
         [&](float* img, int, auto s) {
