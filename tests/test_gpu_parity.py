@@ -391,3 +391,169 @@ def test_low_rank_form_at_full_layer_size(N, dev):
     (dense, n0, r), (lowr, n1, _) = res
     assert n0 == 0 and n1 == 1 and 0 < 4 * r <= D, (n0, n1, r)
     assert _rel(lowr, dense) <= 2e-5
+
+
+# ------------------------------------------------------------------ param groups, odd paths
+def _run_both(N, dev, groups_spec, shapes, transforms_cpu, steps=2, grad_views=None, kind="sgd"):
+    """Run the HIP optimizer and the oracle on the same tensors; return (params_gpu, params_cpu)."""
+    gen = torch.Generator().manual_seed(17)
+    init = {n: torch.randn(s, generator=gen) * 0.05 for n, s in shapes.items()}
+    params = {n: torch.nn.Parameter(init[n].clone().to(dev)) for n in shapes}
+    groups = [dict(params=[params[n] for n in names], **hp) for names, hp in groups_spec]
+    opt = N.SGDNSCL(groups, lr=0.01, svd=True) if kind == "sgd" else N.AdamWNSCL(groups, lr=1e-3, svd=True)
+    for g, (names, _) in zip(opt.param_groups, groups_spec):
+        g["names"] = list(names)
+    for n, P in transforms_cpu.items():
+        opt.transforms[n] = P.to(dev)
+    cpu = {n: init[n].clone() for n in shapes}
+    states = {n: dict() for n in shapes}
+    for step in range(steps):
+        grads = {n: torch.randn(s, generator=gen) for n, s in shapes.items()}
+        if grad_views is None:
+            for n in shapes:
+                params[n].grad = grads[n].clone().to(dev)
+        else:   # all grads are views into ONE flat buffer at deliberately odd (4-byte aligned only) offsets
+            total = sum(v.numel() + 1 for v in grads.values()) + 1
+            flat = torch.zeros(total, device=dev)
+            off = 1
+            for n in shapes:
+                view = flat[off:off + grads[n].numel()].view(shapes[n])
+                view.copy_(grads[n].to(dev))
+                params[n].grad = view
+                off += grads[n].numel() + 1
+        opt.step()
+        for (names, hp), g in zip(groups_spec, opt.param_groups):
+            full = {k: v for k, v in g.items() if k in ("lr", "momentum", "dampening", "weight_decay", "nesterov")}
+            if kind == "sgd":
+                O.sgd_nscl_step(list(names), [cpu[n] for n in names], [grads[n].clone() for n in names],
+                                [states[n] for n in names], transforms_cpu, **full)
+            else:
+                O.adamw_nscl_step(list(names), [cpu[n] for n in names], [grads[n].clone() for n in names],
+                                  [states[n] for n in names], transforms_cpu, lr=g["lr"], betas=g["betas"], eps=g["eps"],
+                                  weight_decay=g["weight_decay"], amsgrad=g["amsgrad"])
+    torch.cuda.synchronize()
+    return opt, params, cpu, init
+
+
+def _check(params, cpu, init, tag):
+    for n in cpu:
+        upd = cpu[n].double() - init[n].double()
+        allowed = REL * upd.abs().max().item() + 4 * 2.0 ** -23 * cpu[n].abs().max().item()
+        assert (params[n].detach().cpu().double() - cpu[n].double()).abs().max().item() <= allowed, (tag, n)
+
+
+def _proj_for(shapes, names):
+    tr = {}
+    for i, n in enumerate(names):
+        s = shapes[n]
+        D = int(np.prod(s[1:]))
+        sv, V = O.eigens(torch.from_numpy(I.covariance_like(D, 70 + i, rows_mult=2)))
+        tr[n] = O.build_projector(V, O.adaptive_threshold(sv, 0.0), "backbone" in n)
+    return tr
+
+
+def test_param_groups_with_different_hyperparameters(N, dev):
+    shapes = {"backbone.a.weight": (128, 128, 1, 1), "backbone.a.bias": (128,), "neck.b.weight": (40, 12, 3, 3),
+              "neck.b.bias": (40,), "roi_head.fc.weight": (24, 33), "backbone.bn.weight": (128,)}
+    tr = _proj_for(shapes, ["backbone.a.weight", "neck.b.weight", "roi_head.fc.weight"])
+    spec = [(["backbone.a.weight", "backbone.a.bias"], dict(lr=0.002, momentum=0.9, weight_decay=1e-4)),
+            (["neck.b.weight", "neck.b.bias", "roi_head.fc.weight"], dict(lr=0.02, momentum=0.8, dampening=0.2, weight_decay=0.0, nesterov=True)),
+            (["backbone.bn.weight"], dict(lr=0.02, momentum=0.0, weight_decay=0.0))]
+    opt, params, cpu, init = _run_both(N, dev, spec, shapes, tr, steps=3)
+    _check(params, cpu, init, "groups")
+    assert len(opt._plans) == 1 and len(opt._plans[0]["groups"]) == 3
+
+
+def test_momentum_zero_and_weight_decay_uses_the_gradient_as_source(N, dev):
+    """momentum = 0: the update source of the projection GEMM is the (weight-decayed) gradient itself."""
+    shapes = {"backbone.a.weight": (128, 256, 1, 1), "neck.b.weight": (20, 12, 3, 3), "x.bias": (7,)}
+    tr = _proj_for(shapes, ["backbone.a.weight", "neck.b.weight"])
+    spec = [(list(shapes), dict(lr=0.05, momentum=0.0, weight_decay=0.01))]
+    opt, params, cpu, init = _run_both(N, dev, spec, shapes, tr, steps=2)
+    _check(params, cpu, init, "momentum0")
+    opt.mutate_grad = False          # the decayed gradient must still reach the GEMM
+    opt2, params2, cpu2, init2 = _run_both(N, dev, spec, shapes, tr, steps=2)
+    _check(params2, cpu2, init2, "momentum0-nomutate")
+
+
+def test_misaligned_gradient_views(N, dev):
+    """Gradients that are 4-byte-aligned views of a flat bucket take the guarded loader (A operand) and the
+    scalar elementwise path; results must not change."""
+    shapes = {"backbone.a.weight": (128, 128, 1, 1), "backbone.c.weight": (256, 128, 1, 1), "neck.b.weight": (20, 12, 3, 3), "x.bias": (7,)}
+    tr = _proj_for(shapes, ["backbone.a.weight", "backbone.c.weight", "neck.b.weight"])
+    for hp in (dict(lr=0.05, momentum=0.0, weight_decay=0.01), dict(lr=0.05, momentum=0.9, nesterov=True, weight_decay=1e-3),
+               dict(lr=0.05, momentum=0.9, weight_decay=1e-3)):
+        opt, params, cpu, init = _run_both(N, dev, [(list(shapes), hp)], shapes, tr, steps=2, grad_views=True)
+        _check(params, cpu, init, f"misaligned {hp}")
+
+
+def test_more_param_groups_than_one_plan_holds(N, dev):
+    """mmengine's paramwise constructor makes one group per parameter: 40 groups -> two plans of <= 32."""
+    shapes = {f"backbone.l{i}.weight": (8, 16, 1, 1) for i in range(40)}
+    tr = _proj_for(shapes, list(shapes)[:5])
+    spec = [([n], dict(lr=0.01 * (1 + i % 3), momentum=0.9, weight_decay=1e-4 * (i % 2))) for i, n in enumerate(shapes)]
+    opt, params, cpu, init = _run_both(N, dev, spec, shapes, tr, steps=2)
+    _check(params, cpu, init, "40 groups")
+    assert len(opt._plans) == 2
+
+
+def test_adamw_param_groups(N, dev):
+    shapes = {"backbone.a.weight": (128, 128, 1, 1), "neck.b.weight": (40, 12, 3, 3), "backbone.bn.weight": (128,)}
+    tr = _proj_for(shapes, ["backbone.a.weight", "neck.b.weight"])
+    spec = [(["backbone.a.weight"], dict(lr=1e-3, weight_decay=0.1)),
+            (["neck.b.weight", "backbone.bn.weight"], dict(lr=1e-4, weight_decay=0.0, betas=(0.8, 0.99), amsgrad=True))]
+    opt, params, cpu, init = _run_both(N, dev, spec, shapes, tr, steps=3, kind="adamw")
+    _check(params, cpu, init, "adamw groups")
+
+
+# ------------------------------------------------------------------ the other BASELINE configs as parity cases
+def test_r101_table_one_step_vs_torch_gpu(N, dev):
+    """configs[4] (R-101-FPN): 101 projected layers, 175.9 GFLOP, one plan."""
+    layers = O.resnet_fpn_projected_layers(101)
+    gen = torch.Generator(device="cpu").manual_seed(8)
+    params, names, Ps, cache = [], [], {}, {}
+    for n, cout, D in layers:
+        k = 3 if (("conv2" in n) or ("fpn_convs" in n)) else 1
+        params.append(torch.nn.Parameter((torch.randn(cout, D // (k * k), k, k, generator=gen) * 0.02).to(dev)))
+        names.append(n)
+        if D not in cache:
+            cache[D] = (torch.randn(D, D, generator=gen) / D ** 0.5).to(dev)
+        Ps[n] = cache[D]
+    opt = N.SGDNSCL(params, lr=0.02, momentum=0.9, weight_decay=1e-4, svd=True)
+    opt.param_groups[0]["names"] = names
+    for n, P in Ps.items():
+        opt.transforms[n] = P
+    before = [p.detach().clone() for p in params]
+    grads = [torch.randn(p.shape, generator=gen).to(dev) for p in params]
+    for p, gr in zip(params, grads):
+        p.grad = gr.clone()
+    opt.step()
+    torch.cuda.synchronize()
+    flops, _, ntiles, nproj = opt.plan_stats()
+    assert nproj == 101 and abs(flops / 1e9 - 175.9) < 0.05 and ntiles == 2778
+    for n, p, p0, gr in zip(names, params, before, grads):
+        upd = -(0.02 * (gr + 1e-4 * p0))
+        exp = p0 + (upd.view(upd.shape[0], -1) @ Ps[n]).view_as(upd)
+        assert _rel(p - p0, exp - p0) <= 2e-5, n
+
+
+def test_coco_40_40_sized_bank_vs_oracle(N, dev):
+    """configs[3] (COCO 40+40 task 2): 40 old classes -> K <= 400 prototypes; ragged class sizes incl. a
+    class with 2 rows.  Masks and labels bit-exact vs the oracle, bank within 1e-5."""
+    from nsgp_repre_amd.roi_heads.prototype_bank import build_prototype_bank
+    D = 1024
+    feats, cls = [], []
+    for c in range(40):
+        n = 2 if c == 7 else 20 + (c * 7) % 50
+        feats.append(I.class_rois(n, D, 9000 + c, n_clusters=3 + c % 4))
+        cls.append(np.full(n, c, dtype=np.int64))
+    feats, cls = torch.from_numpy(np.concatenate(feats)), torch.from_numpy(np.concatenate(cls))
+    bank_ref, lab_ref, masks_ref, _ = O.build_bank(feats, cls, [0, 40, 80], 2, 10)
+    bank, lab, masks, _ = build_prototype_bank(feats.to(dev), cls.to(dev), [0, 40, 80], 2, 10)
+    # a similarity within 1e-5 of the threshold may legitimately flip: skip such classes (none expected)
+    assert torch.equal(lab.cpu(), lab_ref) and bank.shape[0] <= 400
+    for c in range(40):
+        assert len(masks[c]) == len(masks_ref[c])
+        for a, b in zip(masks[c], masks_ref[c]):
+            assert torch.equal(a, b), c
+    assert _rel(bank, bank_ref) <= REL
