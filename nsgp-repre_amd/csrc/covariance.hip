@@ -40,21 +40,57 @@ struct ConvGeom {
     int D, L, Wo, kh, kw, sh, sw, Hp, Wp;
 };
 
-// Stage the 4 rows x 4 columns this thread owns of an implicit X^T tile (rows = d, columns = l).
-__device__ __forceinline__ void stage_im2col(const float* __restrict__ xm, const long (&rowbase)[4], const ConvGeom& g,
-                                             int l0, int l_end, float (&r)[4][4]) {
-    const int t = threadIdx.x;
-    long off[4];
+// Offsets (in floats, relative to a row's base) of the 4 consecutive output positions l0+e this thread
+// stages in one K-step: l = oy*Wo + ox  ->  oy*sh*Wp + ox*sw.  The division by Wo uses a float reciprocal
+// with an exact integer correction (l < 2^24 always: L <= 268,800).  `contig` = the four positions sit in
+// one output row of a stride-1 convolution, i.e. 4 consecutive floats in memory.
+struct PatchCols {
+    long off[4];   // -1 = past the end of this K range
+    bool contig;
+};
+
+__device__ __forceinline__ PatchCols patch_cols(const ConvGeom& g, float inv_wo, int l0, int l_end) {
+    PatchCols pc;
+    const int l = l0 + (threadIdx.x & 7) * 4;
+    int oy = (int)((float)l * inv_wo);
+    oy -= (oy * g.Wo > l);
+    oy += ((oy + 1) * g.Wo <= l);
+    const int ox = l - oy * g.Wo;
+    const long row = (long)oy * g.sh * g.Wp;
+    pc.contig = (g.sw == 1) && (ox + 3 < g.Wo) && (l + 3 < l_end);
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
-        const int l = l0 + (t & 7) * 4 + e;
-        const int oy = l / g.Wo, ox = l - oy * g.Wo;
-        off[e] = (l < l_end) ? ((long)oy * g.sh * g.Wp + (long)ox * g.sw) : -1;
+        int oxe = ox + e;
+        long r = row;
+        while (oxe >= g.Wo) { oxe -= g.Wo; r += (long)g.sh * g.Wp; }   // at most once when Wo >= 4
+        pc.off[e] = (l + e < l_end) ? (r + (long)oxe * g.sw) : -1;
     }
+    return pc;
+}
+
+typedef float f32x4_u __attribute__((ext_vector_type(4), aligned(4)));
+typedef __attribute__((address_space(1))) f32x4_u gf32x4_u;
+
+// Stage the 4 rows x 4 columns this thread owns of an implicit X^T tile (rows = d, columns = l).
+__device__ __forceinline__ void stage_im2col(const float* __restrict__ xm, const long (&rowbase)[4], const PatchCols& pc,
+                                             float (&r)[4][4]) {
+    if (pc.contig) {
 #pragma unroll
-    for (int j = 0; j < 4; ++j)
+        for (int j = 0; j < 4; ++j) {
+            if (rowbase[j] >= 0) {
+                const f32x4_u q = *(const gf32x4_u*)(xm + rowbase[j] + pc.off[0]);   // 4-byte aligned 16-byte load
+                r[j][0] = q[0]; r[j][1] = q[1]; r[j][2] = q[2]; r[j][3] = q[3];
+            } else {
+                r[j][0] = r[j][1] = r[j][2] = r[j][3] = 0.0f;
+            }
+        }
+    } else {
 #pragma unroll
-        for (int e = 0; e < 4; ++e) r[j][e] = (rowbase[j] >= 0 && off[e] >= 0) ? as_global(xm)[rowbase[j] + off[e]] : 0.0f;
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                r[j][e] = (rowbase[j] >= 0 && pc.off[e] >= 0) ? as_global(xm)[rowbase[j] + pc.off[e]] : 0.0f;
+    }
 }
 
 __device__ __forceinline__ void im2col_rowbase(const ConvGeom& g, int d0, long (&rowbase)[4]) {
@@ -89,11 +125,13 @@ __global__ __launch_bounds__(256, 2) void nsgp_cov_syrk_kernel(const float* __re
     im2col_rowbase(g, m0, base_a);
     im2col_rowbase(g, n0, base_b);
     float ra[2][4][4], rb[2][4][4];
+    const float inv_wo = 1.0f / (float)g.Wo;
     mfma_pipeline<true>(
         (l_end - l_beg + BK - 1) / BK, smem, acc,
         [&](int t, auto s) {
-            stage_im2col(xm, base_a, g, l_beg + t * BK, l_end, ra[decltype(s)::value]);
-            stage_im2col(xm, base_b, g, l_beg + t * BK, l_end, rb[decltype(s)::value]);
+            const PatchCols pc = patch_cols(g, inv_wo, l_beg + t * BK, l_end);   // shared by both operands
+            stage_im2col(xm, base_a, pc, ra[decltype(s)::value]);
+            stage_im2col(xm, base_b, pc, rb[decltype(s)::value]);
         },
         [&](float* img, int, auto s) { write_rows(img, ra[decltype(s)::value]); },
         [&](float* img, int, auto s) { write_rows(img, rb[decltype(s)::value]); });
