@@ -60,6 +60,78 @@ def r50_fpn_voc_parameter_table():
     return table
 
 
+def r50_fpn_hooked_convs(H=800, W=1344):
+    """(name, cin, k, stride, pad, Hin, Win) of the 61 convs cal_fea_in hooks on R-50-FPN for one
+    800x1344 padded image (ignore_keys drop rpn/roi_head): sum 2*L*D^2 = 1.86 TFLOP."""
+    out = [("backbone.conv1", 3, 7, 2, 3, H, W)]
+    h, w, inpl = H // 4, W // 4, 64
+    for li, (nb, planes, stride) in enumerate(((3, 64, 1), (4, 128, 2), (6, 256, 2), (3, 512, 2)), start=1):
+        for b in range(nb):
+            st = stride if b == 0 else 1
+            pre = f"backbone.layer{li}.{b}"
+            out.append((pre + ".conv1", inpl, 1, 1, 0, h, w))
+            out.append((pre + ".conv2", planes, 3, st, 1, h, w))
+            h2, w2 = (h + 2 - 3) // st + 1, (w + 2 - 3) // st + 1
+            out.append((pre + ".conv3", planes, 1, 1, 0, h2, w2))
+            if b == 0:
+                out.append((pre + ".downsample.0", inpl, 1, st, 0, h, w))
+            inpl, h, w = planes * 4, h2, w2
+    res = [(H // 4, W // 4), (H // 8, W // 8), (H // 16, W // 16), (H // 32, W // 32)]
+    for i, (c, (hh, ww)) in enumerate(zip((256, 512, 1024, 2048), res)):
+        out.append((f"neck.lateral_convs.{i}.conv", c, 1, 1, 0, hh, ww))
+    for i, (hh, ww) in enumerate(res):
+        out.append((f"neck.fpn_convs.{i}.conv", 256, 3, 1, 1, hh, ww))
+    return out
+
+
+def once_per_task_units(dev):
+    """The other two units of work of SURVEY 8d, timed on their own (never part of `value`):
+    one hooked covariance forward (61 convs, 1.86 TFLOP of reference FLOPs) and the VOC-15+5-sized
+    prototype-bank build (15 old classes x 300 RoIs x 12544)."""
+    from nsgp_repre_amd import ops
+    from nsgp_repre_amd.roi_heads.prototype_bank import build_prototype_bank
+    g = torch.Generator(device=dev).manual_seed(5)
+    layers = r50_fpn_hooked_convs()
+    acts, covs, ws_bytes, ref_flops = {}, {}, 0, 0.0
+    for n, cin, k, s, p, h, w in layers:
+        if (cin, h, w) not in acts:
+            acts[(cin, h, w)] = torch.randn(1, cin, h, w, device=dev, generator=g).abs()
+        ws_bytes = max(ws_bytes, ops.cov_workspace_bytes(cin, h, w, (k, k), (s, s), (p, p)))
+        ho, wo = (h + 2 * p - k) // s + 1, (w + 2 * p - k) // s + 1
+        ref_flops += 2.0 * ho * wo * (cin * k * k) ** 2
+    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+
+    def forward():
+        for n, cin, k, s, p, h, w in layers:
+            covs[n] = ops.cov_accumulate_conv2d(acts[(cin, h, w)], (k, k), (s, s), (p, p), covs.get(n), ws)
+    forward()
+    torch.cuda.synchronize()
+    ts = []
+    for _ in range(3):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(); forward(); e1.record(); torch.cuda.synchronize()
+        ts.append(e0.elapsed_time(e1))
+    cov_ms = sorted(ts)[1]
+    del acts, covs, ws
+    # per class: 4 ReLU'd cluster centres + 0.6 * noise, ReLU'd (SURVEY 8d "Synthetic inputs -- RePRE")
+    centres = torch.relu(torch.randn(15, 4, 12544, device=dev, generator=g))
+    which = torch.randint(0, 4, (15, 300), device=dev, generator=g)
+    feats = torch.relu(torch.gather(centres, 1, which[..., None].expand(-1, -1, 12544))
+                       + 0.6 * torch.randn(15, 300, 12544, device=dev, generator=g)).reshape(15 * 300, 12544).contiguous()
+    cls = torch.arange(15, device=dev).repeat_interleave(300)
+    build_prototype_bank(feats, cls, [0, 15, 20], 2, 10)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    bank, labels, _, _ = build_prototype_bank(feats, cls, [0, 15, 20], 2, 10)
+    torch.cuda.synchronize()
+    bank_ms = (time.perf_counter() - t0) * 1e3
+    return {"covariance_forward_ms": cov_ms, "covariance_reference_flops": ref_flops,
+            "covariance_tflops_by_reference_flops": ref_flops / (cov_ms * 1e-3) / 1e12,
+            "covariance_note": "61 hooked convs of R-50-FPN at 800x1344; only the upper triangle is computed (half the reference FLOPs), X never materialised",
+            "prototype_bank_build_ms": bank_ms, "prototype_bank_rows": int(bank.shape[0]),
+            "prototype_bank_note": "15 old classes x 300 RoIs x 12544 (VOC 15+5 sized), wall time incl. the host-side greedy cover"}
+
+
 def make_basis(D, dev, seed):
     """A random orthonormal eigenbasis V [D x D]; the synthetic rank of the feature space is r = D//16,
     so the projector is V[:, r:] V[:, r:]^T (built by the HIP SYRK kernel through set_basis)."""
@@ -287,6 +359,8 @@ def main():
                                    "achieved_tflops": lr_flops / (lr_gemm_ms * 1e-3) / 1e12, "tiles_phase1": lt1, "tiles_phase2": lt2,
                                    "synthetic_rank": "r = D/16", "note": "opt-in (optimizer.low_rank=True); parity vs the dense form: tests/test_gpu_parity.py::test_low_rank_form_matches_dense_form"}
             opt.low_rank = False
+        if world == 1:
+            out["once_per_task"] = once_per_task_units(dev)
         traffic_file = os.path.join(ROOT, "profiles", "r01_traffic.json")
         if os.path.exists(traffic_file):   # HBM bytes per launch from rocprofv3 --pmc passes of this same command
             tr = json.load(open(traffic_file))
