@@ -49,14 +49,7 @@ def r50_fpn_voc_parameter_table():
             table.append((n.replace(".weight", ".bias"), (cout,), False))
     table += [("rpn_head.rpn_conv.weight", (256, 256, 3, 3), False), ("rpn_head.rpn_conv.bias", (256,), False),
               ("rpn_head.rpn_cls.weight", (3, 256, 1, 1), False), ("rpn_head.rpn_cls.bias", (3,), False),
-              ("rpn_head.rpn_reg.weight", (12, 256, 1, 1), False), ("rpn_head.rpn_reg.bias", (12,), False),
-              ("roi_head.bbox_head.shared_fcs.0.weight", (1024, 12544), False), ("roi_head.bbox_head.shared_fcs.0.bias", (1024,), False),
-              ("roi_head.bbox_head.shared_fcs.1.weight", (1024, 1024), False), ("roi_head.bbox_head.shared_fcs.1.bias", (1024,), False),
-              ("roi_head.bbox_head.fc_cls.0.weight", (15, 1024), False), ("roi_head.bbox_head.fc_cls.0.bias", (15,), False),
-              ("roi_head.bbox_head.fc_cls.1.weight", (5, 1024), False), ("roi_head.bbox_head.fc_cls.1.bias", (5,), False),
-              ("roi_head.bbox_head.fc_cls.2.weight", (1, 1024), False), ("roi_head.bbox_head.fc_cls.2.bias", (1,), False),
-              ("roi_head.bbox_head.fc_reg.0.weight", (60, 1024), False), ("roi_head.bbox_head.fc_reg.0.bias", (60,), False),
-              ("roi_head.bbox_head.fc_reg.1.weight", (20, 1024), False), ("roi_head.bbox_head.fc_reg.1.bias", (20,), False)]
+              ("rpn_head.rpn_reg.weight", (12, 256, 1, 1), False), ("rpn_head.rpn_reg.bias", (12,), False)]
     return table
 
 
@@ -144,23 +137,6 @@ def make_basis(D, dev, seed):
     return V.contiguous(), max(1, D // 16)
 
 
-class ReplayHead(torch.nn.Module):
-    """Shared2FCBBoxHeadTask-shaped classifier branch (convfc_bbox_head_task.py:235-276) for the
-    replay loss (standard_roi_replay_head.py:490-499); weights are views of the optimizer's tensors."""
-
-    def __init__(self, named):
-        super().__init__()
-        self.n = named
-
-    def forward(self, bank, labels, pre_idx):
-        n = self.n
-        h = torch.relu(torch.nn.functional.linear(bank, n["roi_head.bbox_head.shared_fcs.0.weight"], n["roi_head.bbox_head.shared_fcs.0.bias"]))
-        h = torch.relu(torch.nn.functional.linear(h, n["roi_head.bbox_head.shared_fcs.1.weight"], n["roi_head.bbox_head.shared_fcs.1.bias"]))
-        cls = torch.cat([torch.nn.functional.linear(h, n[f"roi_head.bbox_head.fc_cls.{i}.weight"], n[f"roi_head.bbox_head.fc_cls.{i}.bias"]) for i in range(3)], dim=-1)
-        s = torch.cat([cls[:, :pre_idx], cls[:, -1:]], dim=-1)
-        return torch.nn.functional.cross_entropy(s.softmax(dim=-1), labels)
-
-
 def host_cores():
     """Cores this process may actually use: min(affinity, cgroup cpu quota).  (On the GPU box
     os.cpu_count() says 256 while the container's share is 16.)"""
@@ -243,6 +219,14 @@ def main():
     for n, shape, _ in table:
         params.append(torch.nn.Parameter(torch.randn(shape, device=dev, generator=gen) * 0.02))
         names.append(n)
+    # the RoI bbox head is the product's own module (Shared2FCBBoxHeadTask, VOC 15+5 task 2); its 14
+    # tensors join the optimizer table un-projected (ignore_keys=['rpn','roi_head'])
+    bbox_head = N.roi_heads.Shared2FCBBoxHeadTask(in_channels=256, fc_out_channels=1024, roi_feat_size=7, num_classes=20,
+                                                  task_split=[0, 15, 20], task_id=2).to(dev)
+    for n, p in bbox_head.named_parameters():
+        params.append(p)
+        names.append("roi_head.bbox_head." + n)
+        table.append(("roi_head.bbox_head." + n, tuple(p.shape), False))
     opt = N.SGDNSCL(params, lr=0.02, momentum=0.9, weight_decay=1e-4, svd=True)  # schedule_1x_sgdnscl.py:21
     opt.param_groups[0]["names"] = names
     cache = {}
@@ -252,11 +236,14 @@ def main():
             if D not in cache:
                 cache[D] = make_basis(D, dev, 2000 + D)
             opt.set_basis(n, cache[D][0], cache[D][1])      # one [D x D] projector per layer, as in the reference
-    named = dict(zip(names, params))
-    head = ReplayHead(named)
     K = 150  # <= 10 prototypes x 15 old classes (VOC 15+5)
-    bank = torch.relu(torch.randn(K, 12544, device=dev, generator=gen))
-    labels = torch.randint(0, 15, (K,), device=dev, generator=gen)
+
+    class Replay(N.roi_heads.PrototypeReplay):   # the product's replay_loss (head:468-501) on a synthetic bank
+        pass
+    replay = Replay()
+    replay.bbox_head, replay.task_split, replay.task_id, replay.replay = bbox_head, [0, 15, 20], 2, True
+    replay.bbox_featss = torch.relu(torch.randn(K, 12544, device=dev, generator=gen))
+    replay.tmp_label = torch.randint(0, 15, (K,), device=dev, generator=gen)
     # Gradients live in ONE flat bucket with 16-byte-aligned slices (what DDP's
     # gradient_as_bucket_view gives): p.grad are views, filled by "backward" each step.
     offs, total = [], 0
@@ -273,7 +260,7 @@ def main():
 
     def one_step():
         flat_grads.copy_(synth_flat)           # the detector's backward() writes the grads (synthetic)
-        loss = head(bank, labels, 15)          # RePRE replay loss: forward
+        loss = replay.replay_loss(replay.bbox_featss)["replay_loss"]["replay_loss_cls"]   # RePRE replay loss: forward
         loss.backward()                        # + backward: accumulates into the head's grad views
         h0 = time.perf_counter()
         opt.step()                             # NSGP projected step: 2 HIP launches
@@ -328,7 +315,7 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": "R-50-FPN VOC 15+5 task 2 (configs[1]): SGDNSCL step over 50 projected layers "
-                                   "+ 143 plain tensors (41.4M params), replay loss on K=150 prototypes, 1 img/GPU/step",
+                                   "+ 112 plain tensors (41.2M params), replay loss on K=150 prototypes, 1 img/GPU/step",
                        "global_batch": world, "parallelism": f"replicas x{world} (no exchange step on this path)" if world > 1 else "single"},
             "ddp_grad_allreduce_ms": allreduce_ms,
             "roofline": {"bound": "mfma", "kernel": "nsgp_project_kernel<SGD,fast>", "achieved": flops / (gemm_ms * 1e-3) / 1e12,

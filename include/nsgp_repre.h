@@ -181,6 +181,18 @@ int repre_masked_mean(const float* feats, int n, int d, const uint64_t* rowmask,
                       float* out, void* workspace, size_t workspace_bytes, void* stream);
 
 /* ------------------------------------------------------------------------
+ * Replay classifier loss  (K8, the fork's own line)
+ * Replaces F.cross_entropy(cls_score.softmax(dim=-1), labels),
+ * mmdet/models/roi_heads/standard_roi_replay_head.py:499 (double softmax, mean over rows), and its
+ * backward: scores [n_rows x n_cols] fp32 row-major, labels int64 [n_rows], n_cols <= 256.
+ * loss_out / grad_out: device fp32 scalars; grad_scores [n_rows x n_cols].
+ * ------------------------------------------------------------------------ */
+int repre_replay_ce_forward(const float* scores, const int64_t* labels, int n_rows, int n_cols,
+                            float* loss_out, void* stream);
+int repre_replay_ce_backward(const float* scores, const int64_t* labels, int n_rows, int n_cols,
+                             const float* grad_out, float* grad_scores, void* stream);
+
+/* ------------------------------------------------------------------------
  * EWC regulariser on the BatchNorm parameters  
  * Replaces EWCHook.__call__, mmdet/engine/runner/nsrunner_roi_replay.py:1055-1073, which launches
  * ~5 elementwise/reduction kernels per registered parameter (~106 for R-50) every step:

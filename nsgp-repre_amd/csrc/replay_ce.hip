@@ -1,0 +1,112 @@
+// The RePRE replay classifier loss of StandardMultiPrototypeReplayHead.replay_loss
+// (mmdet/models/roi_heads/standard_roi_replay_head.py:499):
+//     loss = F.cross_entropy(cls_score.softmax(dim=-1), labels)          (mean over the K prototypes)
+// i.e. a softmax FOLLOWED by the log-softmax inside cross_entropy -- the reference's double softmax,
+// reproduced.  PyTorch runs softmax, log_softmax, nll_loss (+ their three backward kernels) on a
+// [K x C] matrix with K <= 400 rows and C <= 81 columns: pure launch overhead.  Here one wave64 owns
+// a row: two wave-wide max/sum reductions give q = softmax(s) and lse = logsumexp(q); the forward is a
+// single workgroup (ordered, deterministic mean), the backward one wave per row:
+//     dL/dq_j = (softmax(q)_j - [j == y]) / K,      ds_i = q_i * (dq_i - sum_j dq_j q_j).
+#include "common.hpp"
+
+namespace nsgp {
+
+constexpr int CE_MAX_COLS = 256;   // 4 columns per lane
+
+__device__ __forceinline__ float wave_max(float v) {
+    for (int off = 32; off > 0; off >>= 1) v = fmaxf(v, __shfl_xor(v, off, 64));
+    return v;
+}
+__device__ __forceinline__ float wave_sum(float v) {
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+
+// q (4 per lane) = softmax(row); returns logsumexp(q)
+__device__ __forceinline__ float row_double_softmax(const float* __restrict__ row, int C, int lane, float (&q)[4]) {
+    float m = -INFINITY;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { const int c = lane + 64 * e; q[e] = c < C ? row[c] : -INFINITY; m = fmaxf(m, q[e]); }
+    m = wave_max(m);
+    float s = 0.0f;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { q[e] = (lane + 64 * e < C) ? expf(q[e] - m) : 0.0f; s += q[e]; }
+    s = wave_sum(s);
+    float m2 = -INFINITY;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { q[e] = q[e] / s; if (lane + 64 * e < C) m2 = fmaxf(m2, q[e]); }
+    m2 = wave_max(m2);
+    float s2 = 0.0f;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) if (lane + 64 * e < C) s2 += expf(q[e] - m2);
+    s2 = wave_sum(s2);
+    return m2 + logf(s2);
+}
+
+__global__ __launch_bounds__(256) void repre_replay_ce_fwd_kernel(const float* __restrict__ scores, const long long* __restrict__ labels,
+                                                                  int K, int C, float* __restrict__ loss_out) {
+    __shared__ float part[4];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    float acc = 0.0f;
+    for (int r = wave; r < K; r += 4) {
+        float q[4];
+        const float lse = row_double_softmax(scores + (long)r * C, C, lane, q);
+        const int y = (int)labels[r];
+        float qy = 0.0f;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) if (lane + 64 * e == y) qy = q[e];
+        qy = wave_sum(qy);
+        acc += lse - qy;                 // -log_softmax(q)[y]
+    }
+    if (lane == 0) part[wave] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) *loss_out = ((part[0] + part[1]) + (part[2] + part[3])) / (float)K;
+}
+
+__global__ __launch_bounds__(256) void repre_replay_ce_bwd_kernel(const float* __restrict__ scores, const long long* __restrict__ labels,
+                                                                  int K, int C, const float* __restrict__ grad_out,
+                                                                  float* __restrict__ grad_scores) {
+    const int lane = threadIdx.x & 63;
+    const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= K) return;
+    float q[4];
+    const float lse = row_double_softmax(scores + (long)r * C, C, lane, q);
+    const int y = (int)labels[r];
+    const float go = *grad_out / (float)K;
+    float dq[4], dot = 0.0f;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const int c = lane + 64 * e;
+        dq[e] = (c < C) ? go * (expf(q[e] - lse) - (c == y ? 1.0f : 0.0f)) : 0.0f;
+        dot += dq[e] * q[e];
+    }
+    dot = wave_sum(dot);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const int c = lane + 64 * e;
+        if (c < C) grad_scores[(long)r * C + c] = q[e] * (dq[e] - dot);
+    }
+}
+
+}  // namespace nsgp
+
+using namespace nsgp;
+
+extern "C" int repre_replay_ce_forward(const float* scores, const int64_t* labels, int n_rows, int n_cols, float* loss_out, void* stream_) {
+    if (!scores || !labels || !loss_out || n_rows <= 0 || n_cols <= 0) return fail(NSGP_ERR_INVALID, "repre_replay_ce_forward: bad argument");
+    if (n_cols > CE_MAX_COLS) return fail(NSGP_ERR_LIMIT, "repre_replay_ce_forward: %d columns > %d", n_cols, CE_MAX_COLS);
+    hipLaunchKernelGGL(repre_replay_ce_fwd_kernel, dim3(1), dim3(256), 0, static_cast<hipStream_t>(stream_), scores,
+                       reinterpret_cast<const long long*>(labels), n_rows, n_cols, loss_out);
+    NSGP_LAUNCH_CHECK();
+    return NSGP_OK;
+}
+
+extern "C" int repre_replay_ce_backward(const float* scores, const int64_t* labels, int n_rows, int n_cols, const float* grad_out,
+                                        float* grad_scores, void* stream_) {
+    if (!scores || !labels || !grad_out || !grad_scores || n_rows <= 0 || n_cols <= 0) return fail(NSGP_ERR_INVALID, "repre_replay_ce_backward: bad argument");
+    if (n_cols > CE_MAX_COLS) return fail(NSGP_ERR_LIMIT, "repre_replay_ce_backward: %d columns > %d", n_cols, CE_MAX_COLS);
+    hipLaunchKernelGGL(repre_replay_ce_bwd_kernel, dim3((n_rows + 3) / 4), dim3(256), 0, static_cast<hipStream_t>(stream_), scores,
+                       reinterpret_cast<const long long*>(labels), n_rows, n_cols, grad_out, grad_scores);
+    NSGP_LAUNCH_CHECK();
+    return NSGP_OK;
+}

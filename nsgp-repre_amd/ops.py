@@ -143,6 +143,35 @@ def masked_mean(feats: torch.Tensor, rowmask_words: torch.Tensor = None, n_selec
     return out
 
 
+class _DoubleSoftmaxCE(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, scores, labels):
+        lib = _lib.load_library()
+        K, Cn = scores.shape
+        loss = torch.empty((), dtype=torch.float32, device=scores.device)
+        _lib.check(lib.repre_replay_ce_forward(_dev(scores, "scores"), _dev(labels, "labels", torch.int64), K, Cn,
+                                               C.c_void_p(loss.data_ptr()), _stream()), "repre_replay_ce_forward")
+        ctx.save_for_backward(scores, labels)
+        return loss
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        scores, labels = ctx.saved_tensors
+        lib = _lib.load_library()
+        K, Cn = scores.shape
+        go = grad_out.detach().reshape(()).float().contiguous()
+        grad = torch.empty_like(scores)
+        _lib.check(lib.repre_replay_ce_backward(_dev(scores, "scores"), _dev(labels, "labels", torch.int64), K, Cn,
+                                                C.c_void_p(go.data_ptr()), _dev(grad, "grad"), _stream()), "repre_replay_ce_backward")
+        return grad, None
+
+
+def double_softmax_cross_entropy(scores: torch.Tensor, labels: torch.Tensor) -> torch.Tensor:
+    """``F.cross_entropy(scores.softmax(-1), labels)`` -- the replay classifier loss of
+    standard_roi_replay_head.py:499 -- as one fused forward and one fused backward launch."""
+    return _DoubleSoftmaxCE.apply(scores.float().contiguous(), labels.contiguous())
+
+
 def pseudo_label_filter(boxes: torch.Tensor, scores: torch.Tensor, gt_boxes: torch.Tensor, rpn_thresh: float,
                         roi_thresh: float, iou_thresh: float = 0.7):
     """Sequential teacher pseudo-label filter of one image -> (add_to_rpn bool[P], add_to_roi bool[P]) --

@@ -81,7 +81,11 @@ class PrototypeReplay:
         results = dict(cls_score=cls_score, bbox_pred=bbox_pred, bbox_feats=bbox_feats)
         pre_idx = self.task_split[self.task_id]
         kept = torch.cat([cls_score[:, :pre_idx], cls_score[:, -1:]], dim=-1)
-        loss = F.cross_entropy(kept.softmax(dim=-1), self.tmp_label.to(kept.device))
+        labels = self.tmp_label.to(kept.device)
+        if kept.is_cuda and kept.dtype == torch.float32 and kept.shape[1] <= 256:
+            loss = ops.double_softmax_cross_entropy(kept, labels)        # fused wave-reduction kernels
+        else:   # CPU tensors (tests of the host logic) / autocast dtypes: the same formula through torch
+            loss = F.cross_entropy(kept.softmax(dim=-1), labels)
         results.update(replay_loss=dict(replay_loss_cls=loss))
         return results
 

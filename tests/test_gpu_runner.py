@@ -242,3 +242,27 @@ def test_pseudo_label_filter_vs_oracle(N, dev):
             if ref_roi[2]:
                 assert not ref_roi[5] and not ref_roi[9]    # the sequential dependency is exercised
             assert bool((ref_roi <= ref_rpn).all())          # roi_thresh >= rpn_thresh
+
+
+def test_fused_double_softmax_ce_vs_torch_and_golden(N, dev, golden_dir):
+    """head:499 ``F.cross_entropy(cls_score.softmax(-1), labels)``: fused kernels vs torch's own ops
+    (fp64 reference) on ragged sizes, and vs the reference's loss value of G5."""
+    from nsgp_repre_amd import ops
+    g = torch.Generator().manual_seed(4)
+    for K, Cn in ((150, 21), (1, 2), (400, 81), (37, 130), (5, 256)):
+        s = torch.randn(K, Cn, generator=g) * 3
+        y = torch.randint(0, Cn, (K,), generator=g)
+        s64 = s.double().requires_grad_(True)
+        ref = torch.nn.functional.cross_entropy(s64.softmax(-1), y)
+        ref.backward()
+        sd = s.to(dev).requires_grad_(True)
+        out = ops.double_softmax_cross_entropy(sd, y.to(dev))
+        (out * 2.0).backward()
+        assert abs(out.item() - ref.item()) <= 1e-6 * abs(ref.item()) + 1e-7
+        assert _rel(sd.grad, 2.0 * s64.grad) <= 1e-5
+    gold = np.load(os.path.join(golden_dir, "g5_replay_loss.npz"))
+    sc = torch.from_numpy(gold["cls_score"])
+    kept = torch.cat([sc[:, :I.G5_TASK_SPLIT[I.G5_TASK_ID]], sc[:, -1:]], dim=-1).contiguous()
+    _, labels = I.g5_bank()
+    out = ops.double_softmax_cross_entropy(kept.to(dev), torch.from_numpy(labels).to(dev))
+    np.testing.assert_allclose(out.item(), gold["loss"], rtol=1e-6)
