@@ -263,6 +263,42 @@ __device__ __forceinline__ void load4(const float* const (&ptr)[4], long off, fl
     }
 }
 
+// ---- epilogue re-layout: accumulators -> LDS -> one float4 per lane along the row ---------------
+// The MFMA C/D layout gives a lane 64 scattered scalars (column on the lane, 16 rows in registers):
+// an epilogue that touches 2-3 global arrays per element then issues ~200 dword memory instructions
+// per wave.  For short-K tiles that IS the kernel.  After the last barrier of the K loop each wave
+// parks its 64x64 block in its own LDS slice (row stride 64 floats: conflict-free dword writes, 16-byte
+// aligned rows) and re-reads it as float4 rows: lane l, pass i -> row 4i + (l>>4), columns 4(l&15)..+3,
+// i.e. every wave-instruction moves four full 256-byte row segments.
+constexpr int EPI_LD = 64;
+static_assert(4 * 64 * EPI_LD <= SMEM_FLOATS, "epilogue slices must fit the K-loop LDS");
+
+__device__ __forceinline__ void acc_to_lds(float* smem, const f32x16 (&acc)[2][2]) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    float* mine = smem + wave * 64 * EPI_LD;
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                mine[(mi * 32 + acc_row(r, lane)) * EPI_LD + ni * 32 + (lane & 31)] = acc[mi][ni][r];
+}
+
+// f(row_in_tile, col_in_tile, float4 acc_values) for this wave's 64x64 block, 16 passes
+template <class F>
+__device__ __forceinline__ void for_each_row4(const float* smem, F f) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const float* mine = smem + wave * 64 * EPI_LD;
+#pragma unroll 4
+    for (int i = 0; i < 16; ++i) {
+        const int row = 4 * i + (lane >> 4), col = 4 * (lane & 15);
+        const float4 v = *reinterpret_cast<const float4*>(mine + row * EPI_LD + col);
+        f(wm * 64 + row, wn * 64 + col, v);
+    }
+}
+
 // ---- dense tile: acc = A[m0.., :] x B (callers apply any scalar factor in their epilogue) ------------------------------------------------
 // A: [M x K] row-major (lda).  B_ROWS=false: B is [K x N] row-major (ldb), n contiguous.
 // B_ROWS=true: B is given as [N x K] row-major (ldb), i.e. acc = A x B^T.

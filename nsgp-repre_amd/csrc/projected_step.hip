@@ -232,7 +232,21 @@ __global__ __launch_bounds__(256, 2) void nsgp_project_kernel(const TileDev* __r
         gemm_tile<false, true, false>(A, L.cols, L.proj, L.cols, L.rows, L.cols, L.cols, t.m0, t.n0, smem, acc);
     // p.data.add_(update_) :95 with update_ = (-(lr*S)) @ P; the scalar is applied once per output
     // element here instead of once per staged operand element (differs by one fp32 rounding per term)
-    store_tile<FAST, true>(L.p, L.cols, L.rows, L.cols, t.m0, t.n0, acc, scale);
+    if (FAST) {   // full tile, 16-byte aligned p: re-layout through LDS and update p with float4 read-modify-writes
+        acc_to_lds(smem, acc);
+        __builtin_amdgcn_s_waitcnt(0xc07f);    // lgkmcnt(0): this wave's own LDS writes have landed
+        for_each_row4(smem, [&](int r, int col, float4 v) {
+            gf32x4* pp = (gf32x4*)(L.p + (long)(t.m0 + r) * L.cols + t.n0 + col);
+            f32x4 pv = *pp;
+            pv[0] = pv[0] + scale * v.x;
+            pv[1] = pv[1] + scale * v.y;
+            pv[2] = pv[2] + scale * v.z;
+            pv[3] = pv[3] + scale * v.w;
+            *pp = pv;
+        });
+    } else {
+        store_tile<FAST, true>(L.p, L.cols, L.rows, L.cols, t.m0, t.n0, acc, scale);
+    }
 }
 
 template <bool FAST>
@@ -329,22 +343,23 @@ __global__ __launch_bounds__(256, 2) void nsgp_lowrank_p2_kernel(const TileDev* 
         },
         [&](float* img, int kt, auto s) { write_rows_khi(img, ra[decltype(s)::value], kt * BK, L.rank); },
         [&](float* img, int kt, auto s) { write_rows_khi(img, rb[decltype(s)::value], kt * BK, L.rank); });
-    // p += c * (scale*S - T U^T)
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int wm = wave >> 1, wn = wave & 1;
-    const gfloat* Ag = as_global(A);
-    gfloat* Pg = as_global(L.p);
-#pragma unroll
-    for (int mi = 0; mi < 2; ++mi)
-#pragma unroll
-        for (int ni = 0; ni < 2; ++ni) {
-            const int col = t.n0 + wn * 64 + ni * 32 + (lane & 31);
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const long idx = (long)(t.m0 + wm * 64 + mi * 32 + acc_row(r, lane)) * L.cols + col;
-                Pg[idx] = Pg[idx] + L.basis_scale * (scale * Ag[idx] - acc[mi][ni][r]);
-            }
-        }
+    // p += c * (scale*S - T U^T), 16 bytes per lane (the K loop is only r/32 steps long: the epilogue,
+    // three global arrays per element, would otherwise dominate this kernel)
+    __syncthreads();                       // every wave is done reading the K-loop images
+    acc_to_lds(smem, acc);
+    __builtin_amdgcn_s_waitcnt(0xc07f);    // lgkmcnt(0): this wave's own LDS writes have landed
+    const float c = L.basis_scale;
+    for_each_row4(smem, [&](int r, int col, float4 v) {
+        const long idx = (long)(t.m0 + r) * L.cols + t.n0 + col;
+        const f32x4 a = *(const gf32x4*)(A + idx);
+        gf32x4* pp = (gf32x4*)(L.p + idx);
+        f32x4 pv = *pp;
+        pv[0] = pv[0] + c * (scale * a[0] - v.x);
+        pv[1] = pv[1] + c * (scale * a[1] - v.y);
+        pv[2] = pv[2] + c * (scale * a[2] - v.z);
+        pv[3] = pv[3] + c * (scale * a[3] - v.w);
+        *pp = pv;
+    });
 }
 
 // ---- host: plan ---------------------------------------------------------------
