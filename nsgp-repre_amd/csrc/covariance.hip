@@ -136,6 +136,15 @@ __global__ __launch_bounds__(256, 2) void nsgp_cov_syrk_kernel(const float* __re
         [&](float* img, int, auto s) { write_rows(img, ra[decltype(s)::value]); },
         [&](float* img, int, auto s) { write_rows(img, rb[decltype(s)::value]); });
     float* out = partial + (long)blockIdx.y * g.D * g.D;
+    if (g.D % BM == 0) {   // full tiles: park the block in LDS, store float4 rows (short K chunks make the store matter)
+        acc_to_lds(smem, acc);
+        for_each_row4(smem, [&](int r, int col, float4 v) {
+            f32x4 q;
+            q[0] = v.x; q[1] = v.y; q[2] = v.z; q[3] = v.w;
+            *(gf32x4*)(out + (long)(m0 + r) * g.D + n0 + col) = q;
+        });
+        return;
+    }
 #pragma unroll
     for (int mi = 0; mi < 2; ++mi)
 #pragma unroll

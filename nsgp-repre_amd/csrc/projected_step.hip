@@ -305,7 +305,13 @@ __global__ __launch_bounds__(256, 2) void nsgp_lowrank_p1_kernel(const TileDev* 
         },
         [&](float* img, int, auto s) { write_rows(img, ra[decltype(s)::value]); },
         [&](float* img, int, auto s) { write_kn(img, rb[decltype(s)::value]); });
-    store_tile<true, false>(L.slabs + (long)t.pad * L.rows * L.rpad, L.rpad, L.rows, L.rpad, t.m0, t.n0, acc, scale);
+    float* slab = L.slabs + (long)t.pad * L.rows * L.rpad;
+    acc_to_lds(smem, acc);
+    for_each_row4(smem, [&](int r, int col, float4 v) {
+        f32x4 q;
+        q[0] = scale * v.x; q[1] = scale * v.y; q[2] = scale * v.z; q[3] = scale * v.w;
+        *(gf32x4*)(slab + (long)(t.m0 + r) * L.rpad + t.n0 + col) = q;
+    });
 }
 
 __global__ __launch_bounds__(256) void nsgp_lowrank_reduce_kernel(const ChunkDev* __restrict__ chunks,

@@ -557,3 +557,37 @@ def test_coco_40_40_sized_bank_vs_oracle(N, dev):
         for a, b in zip(masks[c], masks_ref[c]):
             assert torch.equal(a, b), c
     assert _rel(bank, bank_ref) <= REL
+
+
+def test_step_is_bitwise_deterministic(N, dev):
+    """No float atomics anywhere on the path: two runs from the same state give the same bits
+    (dense and low-rank form, covariance, prototype selection)."""
+    from nsgp_repre_amd import ops
+    shapes = {"backbone.a.weight": (256, 128, 3, 3), "neck.b.weight": (128, 512, 1, 1), "backbone.bn.weight": (300,)}
+    cov = {n: torch.from_numpy(I.covariance_like(int(np.prod(s[1:])), 90 + i, rows_mult=2)).to(dev)
+           for i, (n, s) in enumerate(shapes.items()) if len(s) == 4}
+    for low in (False, True):
+        outs = []
+        for rep in range(2):
+            gen = torch.Generator().manual_seed(3)
+            params = [torch.nn.Parameter((torch.randn(s, generator=gen) * 0.02).to(dev)) for s in shapes.values()]
+            opt = N.SGDNSCL(params, lr=0.02, momentum=0.9, weight_decay=1e-4, svd=True)
+            opt.param_groups[0]["names"] = list(shapes)
+            opt.low_rank = low
+            opt.get_eigens(cov)
+            opt.get_transforms()
+            for step in range(3):
+                for p in params:
+                    p.grad = torch.randn(p.shape, generator=gen).to(dev)
+                opt.step()
+            torch.cuda.synchronize()
+            outs.append([p.detach().clone() for p in params] + [opt.transforms[n].clone() for n in cov])
+        for a, b in zip(*outs):
+            assert torch.equal(a, b), low
+    x = torch.randn(2, 64, 40, 56, generator=torch.Generator().manual_seed(1)).to(dev)
+    c1 = ops.cov_accumulate_conv2d(x, (3, 3), (1, 1), (1, 1))
+    c2 = ops.cov_accumulate_conv2d(x, (3, 3), (1, 1), (1, 1))
+    assert torch.equal(c1, c2)
+    F_ = torch.from_numpy(I.class_rois(200, 512, 8, n_clusters=5)).to(dev)
+    (k1, b1), (k2, b2) = ops.sim_counts(F_), ops.sim_counts(F_)
+    assert torch.equal(k1, k2) and torch.equal(b1, b2)
