@@ -200,6 +200,8 @@ def main():
     ap.add_argument("--steps", type=int, default=30)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--amp", action="store_true", help="run the replay head's GEMMs under bf16 autocast (measured 7x SLOWER "
+                    "than fp32 on this image's hipBLASLt for the M=150 shapes: 12.4 vs 1.66 ms per step, so off by default)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", 0))
@@ -260,7 +262,8 @@ def main():
 
     def one_step():
         flat_grads.copy_(synth_flat)           # the detector's backward() writes the grads (synthetic)
-        loss = replay.replay_loss(replay.bbox_featss)["replay_loss"]["replay_loss_cls"]   # RePRE replay loss: forward
+        with torch.autocast("cuda", dtype=torch.bfloat16, enabled=args.amp):   # configs[1] trains under bf16 autocast (--amp)
+            loss = replay.replay_loss(replay.bbox_featss)["replay_loss"]["replay_loss_cls"]   # RePRE replay loss: forward
         loss.backward()                        # + backward: accumulates into the head's grad views
         h0 = time.perf_counter()
         opt.step()                             # NSGP projected step: 2 HIP launches
@@ -316,6 +319,7 @@ def main():
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": "R-50-FPN VOC 15+5 task 2 (configs[1]): SGDNSCL step over 50 projected layers "
                                    "+ 112 plain tensors (41.2M params), replay loss on K=150 prototypes, 1 img/GPU/step",
+                       "autocast": "bf16 for the replay head's GEMMs (as tools/train.py --amp does for the detector); parameters, gradients, optimizer state and the whole NSGP step fp32" if args.amp else "off",
                        "global_batch": world, "parallelism": f"replicas x{world} (no exchange step on this path)" if world > 1 else "single"},
             "ddp_grad_allreduce_ms": allreduce_ms,
             "roofline": {"bound": "mfma", "kernel": "nsgp_project_kernel<SGD,fast>", "achieved": flops / (gemm_ms * 1e-3) / 1e12,
