@@ -208,11 +208,18 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", 0))
     world = int(os.environ.get("WORLD_SIZE", 1))
     import torch.distributed as dist
-    if world > 1:
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    # rehearsal knobs (single-GPU box): NSGP_BENCH_ONE_DEVICE=1 puts every rank on cuda:0 and
+    # NSGP_BENCH_BACKEND=gloo replaces RCCL (which refuses two ranks on one device); never set by the driver
+    if os.environ.get("NSGP_BENCH_ONE_DEVICE") == "1":
+        local_rank = 0
+    backend = os.environ.get("NSGP_BENCH_BACKEND", "nccl")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    if world > 1:
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
     import nsgp_repre_amd as N
 
     table = r50_fpn_voc_parameter_table()
