@@ -50,7 +50,12 @@ class NSCLOptimizerBase(Optimizer):
         for group in self.param_groups:
             group.setdefault("svd", False)
             group.setdefault("names", [])
+        # load_state_dict() replaces every state tensor: the plans hold the old pointers
+        if getattr(self, "_plans", None):
+            self._destroy_plans()
         self._plans, self._plan_key, self._workspaces = [], None, []
+        if not hasattr(self, "_basis"):
+            self._basis, self.low_rank, self.mutate_grad = {}, False, True
 
     def __del__(self):
         try:
@@ -90,6 +95,32 @@ class NSCLOptimizerBase(Optimizer):
             eigen = self.eigens[n]
             eigen["eigen_value"] = s[order].contiguous()
             eigen["eigen_vector"] = Q[:, order].contiguous()
+        if distinguisher is not None:
+            self.plot_sval_figures(self.eigens, distinguisher)
+
+    def plot_sval_figures(self, svals_dict, distinguisher=None, offset=0.0):
+        """Spectrum plots, kept / null-space parts in two colours, one panel per layer, written to
+        ``./figures/svals_task1_<distinguisher>.png`` (SGD_NSCL.py:180-201; host-side matplotlib)."""
+        import os
+        import matplotlib
+        matplotlib.use("Agg")
+        import matplotlib.pyplot as plt
+        keys = list(svals_dict.keys())
+        fig, axes = plt.subplots(len(keys) // 4 + 1, 4, squeeze=False)
+        fig.set_figheight(60)
+        fig.set_figwidth(15)
+        for i, k in enumerate(keys):
+            sv = svals_dict[k]["eigen_value"]
+            pts = sv.detach().cpu().numpy()
+            i_thres = elbow_index(pts, offset, self._threshold_rule)
+            ax = axes[i // 4, i % 4]
+            ax.plot(np.arange(i_thres + 1), pts[:i_thres + 1], color="blue")
+            ax.plot(np.arange(i_thres, len(pts)), pts[i_thres:], color="red")
+            ax.set_title(k)
+        os.makedirs("./figures", exist_ok=True)
+        fig.tight_layout()
+        fig.savefig(os.path.join("./figures", f"svals_task{1}_{distinguisher}.png"))
+        plt.close(fig)
 
     def _null_space_start(self, group, n):
         """Index of the first basis column kept (the mask is always a suffix)."""
@@ -249,13 +280,14 @@ class NSCLOptimizerBase(Optimizer):
             with torch.enable_grad():
                 loss = closure()
         lib = _lib.load_library()
-        transforms = self.transforms
+        transforms, state = self.transforms, self.state
         key = [bool(self.low_rank)]
         for gi, group in enumerate(self.param_groups):
             svd = group["svd"]
             for n, p in zip(group["names"], group["params"]):
                 P = transforms.get(n) if (svd and n in transforms) else None
-                key.append((p.data_ptr(), gi, P.data_ptr() if isinstance(P, torch.Tensor) else 0))
+                # id(state dict): load_state_dict / a manual swap replaces the state tensors the plan points at
+                key.append((p.data_ptr(), gi, P.data_ptr() if isinstance(P, torch.Tensor) else 0, id(state[p])))
         if len(key) == 1:
             return loss
         key = tuple(key)

@@ -591,3 +591,45 @@ def test_step_is_bitwise_deterministic(N, dev):
     F_ = torch.from_numpy(I.class_rois(200, 512, 8, n_clusters=5)).to(dev)
     (k1, b1), (k2, b2) = ops.sim_counts(F_), ops.sim_counts(F_)
     assert torch.equal(k1, k2) and torch.equal(b1, b2)
+
+
+def test_state_dict_round_trip_keeps_stepping_correctly(N, dev):
+    """Optimizer.load_state_dict replaces every state tensor; the step plans must follow (a stale
+    momentum-buffer pointer would silently train on freed memory)."""
+    shapes = {"backbone.a.weight": (128, 128, 1, 1), "x.bias": (9,)}
+    tr = _proj_for(shapes, ["backbone.a.weight"])
+    hp = dict(lr=0.05, momentum=0.9, weight_decay=1e-3)
+    gen = torch.Generator().manual_seed(2)
+    init = {n: torch.randn(s, generator=gen) * 0.05 for n, s in shapes.items()}
+    grads = [{n: torch.randn(s, generator=gen) for n, s in shapes.items()} for _ in range(4)]
+
+    def make():
+        params = {n: torch.nn.Parameter(init[n].clone().to(dev)) for n in shapes}
+        opt = N.SGDNSCL(list(params.values()), svd=True, **hp)
+        opt.param_groups[0]["names"] = list(shapes)
+        for n, P in tr.items():
+            opt.transforms[n] = P.to(dev)
+        return params, opt
+
+    def run(params, opt, steps):
+        for g in steps:
+            for n in shapes:
+                params[n].grad = g[n].clone().to(dev)
+            opt.step()
+    pa, oa = make()
+    run(pa, oa, grads)                        # 4 uninterrupted steps
+    pb, ob = make()
+    run(pb, ob, grads[:2])
+    sd = ob.state_dict()
+    pc, oc = make()
+    with torch.no_grad():
+        for n in shapes:
+            pc[n].copy_(pb[n])
+    oc.load_state_dict(sd)                    # fresh optimizer, state restored
+    oc.param_groups[0]["names"] = list(shapes)
+    run(pc, oc, grads[2:])
+    ob.load_state_dict(ob.state_dict())       # and a self round trip on a live optimizer (plans must be rebuilt)
+    run(pb, ob, grads[2:])
+    torch.cuda.synchronize()
+    for n in shapes:
+        assert torch.equal(pa[n], pc[n]) and torch.equal(pa[n], pb[n]), n

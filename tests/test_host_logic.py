@@ -138,3 +138,19 @@ def test_ops_refuse_cpu(N):
         ops.sim_counts(torch.ones(4, 8))
     with pytest.raises(RuntimeError, match="GPU tensor"):
         ops.cov_accumulate_conv2d(torch.ones(1, 2, 4, 4), (3, 3), (1, 1), (1, 1))
+
+
+def test_spectrum_plot_is_written(N, tmp_path, monkeypatch):
+    """get_eigens(..., distinguisher=...) plots like the reference (SGD_NSCL.py:383-384); CPU tensors are
+    fine for this host-side part."""
+    monkeypatch.chdir(tmp_path)
+    p = torch.nn.Parameter(torch.zeros(4, 16))
+    opt = N.SGDNSCL([p], svd=True)
+    opt.param_groups[0]["names"] = ["fc.weight"]
+    C = torch.from_numpy(I.covariance_like(16, 3))
+    opt.get_eigens({"fc.weight": C}, distinguisher="unit")
+    assert (tmp_path / "figures" / "svals_task1_unit.png").exists()
+    sv = opt.eigens["fc.weight"]["eigen_value"]
+    assert bool((sv[:-1] >= sv[1:]).all())
+    V = opt.eigens["fc.weight"]["eigen_vector"]
+    assert torch.allclose(V @ torch.diag(sv) @ V.t(), C, rtol=1e-3, atol=1e-3 * float(C.abs().max()))
