@@ -620,7 +620,8 @@ def test_state_dict_round_trip_keeps_stepping_correctly(N, dev):
     run(pa, oa, grads)                        # 4 uninterrupted steps
     pb, ob = make()
     run(pb, ob, grads[:2])
-    sd = ob.state_dict()
+    import copy
+    sd = copy.deepcopy(ob.state_dict())       # state_dict() hands out the live tensors: copy, or oc would share ob's buffers
     pc, oc = make()
     with torch.no_grad():
         for n in shapes:
