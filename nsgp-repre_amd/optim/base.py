@@ -40,6 +40,8 @@ class NSCLOptimizerBase(Optimizer):
         #: opt-in: apply projectors built by get_transforms in their low-rank form
         #: p += c*(u - (u U)U^T) (4*Cout*D*r FLOP) when r <= D/4; the dense u @ P is the parity path
         self.low_rank = False
+        #: with low_rank: orthonormalise the eigenbasis (one Newton-Schulz step) before building P from it
+        self.polish_basis = True
         self._basis = {}
         self._plans = []
         self._plan_key = None
@@ -55,7 +57,7 @@ class NSCLOptimizerBase(Optimizer):
             self._destroy_plans()
         self._plans, self._plan_key, self._workspaces = [], None, []
         if not hasattr(self, "_basis"):
-            self._basis, self.low_rank, self.mutate_grad = {}, False, True
+            self._basis, self.low_rank, self.mutate_grad, self.polish_basis = {}, False, True, True
 
     def __del__(self):
         try:
@@ -151,6 +153,13 @@ class NSCLOptimizerBase(Optimizer):
         SYRK kernel, and remember ``(V, rank)`` so that ``low_rank=True`` can apply it as
         ``u - (u U) U^T``."""
         normalise = self._normalise(name) if normalise is None else normalise
+        if self.low_rank and self.polish_basis:
+            # V_tail V_tail^T == I - U U^T only for an orthonormal V; an fp32 eigh of a 4608-wide matrix is
+            # orthonormal to ~1e-5, which shows up as a 1e-5 difference between the two forms of the step.
+            # One Newton-Schulz step V <- V (1.5 I - 0.5 V^T V) squares that error (once per layer per task;
+            # two library GEMMs).  Both forms are then built from the SAME polished basis.
+            G = V.t() @ V
+            V = (1.5 * V - 0.5 * (V @ G)).contiguous()
         P, norm = ops.build_projector(V, int(rank), normalise, return_norm=True)
         self.transforms[name] = P.detach_()
         self._basis[name] = dict(V=V, rank=int(rank), norm=norm, P_ptr=P.data_ptr())

@@ -368,9 +368,9 @@ def test_set_basis_builds_the_projector(N, dev):
 def test_low_rank_form_at_full_layer_size(N, dev):
     """The largest R-50 layer shape (512 x 4608): eigh on the GPU -> projector; low-rank vs dense form
     of ONE SGD step.  This is where the orthogonality error of a 4608-wide fp32 eigenbasis shows:
-    V_tail V_tail^T and I - U U^T are only equal for exactly orthonormal V.  Measured 1.06e-5 of
-    max|update| -- just OUTSIDE the 1e-5 gate, which is why the low-rank form is opt-in and the dense
-    form is the parity path.  The bound here documents that measurement."""
+    V_tail V_tail^T and I - U U^T are only equal for exactly orthonormal V.  With the raw eigh basis
+    the two forms differ by 1.06e-5 of max|update| (just outside the gate); with the basis polished by
+    one Newton-Schulz step (what low_rank=True does by default) they agree inside it."""
     rows, D = 512, 4608
     g = torch.Generator(device=dev).manual_seed(21)
     X = torch.randn(2 * D, D, device=dev, generator=g) * torch.logspace(0, -3, D, device=dev)
@@ -381,16 +381,17 @@ def test_low_rank_form_at_full_layer_size(N, dev):
         p = torch.nn.Parameter(torch.zeros(rows, D // 9, 3, 3, device=dev))
         opt = N.SGDNSCL([p], lr=0.02, momentum=0.9, svd=True)
         opt.param_groups[0]["names"] = ["backbone.layer4.0.conv2.weight"]
-        opt.low_rank = low
+        opt.low_rank = True            # both runs build P from the polished basis ...
         opt.get_eigens({"backbone.layer4.0.conv2.weight": C})
         opt.get_transforms()
+        opt.low_rank = low             # ... and differ only in the form of the step
         p.grad = grad.clone()
         opt.step()
         torch.cuda.synchronize()
         res.append((p.detach().clone(), opt.lowrank_stats()[0], opt._basis["backbone.layer4.0.conv2.weight"]["rank"]))
     (dense, n0, r), (lowr, n1, _) = res
     assert n0 == 0 and n1 == 1 and 0 < 4 * r <= D, (n0, n1, r)
-    assert _rel(lowr, dense) <= 2e-5
+    assert _rel(lowr, dense) <= REL
 
 
 # ------------------------------------------------------------------ param groups, odd paths
