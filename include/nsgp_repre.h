@@ -220,6 +220,17 @@ int repre_pseudo_label_filter(const float* boxes, const float* scores, int n_box
                               int n_gt, float iou_thr, float rpn_thr, float roi_thr,
                               unsigned char* add_rpn, unsigned char* add_roi, void* stream);
 
+/* ------------------------------------------------------------------------
+ * Greedy box NMS  (support for the teacher's per-step `predict`, det:72-74)
+ * Replaces mmcv.ops.nms / batched_nms (mmcv is not part of the reference tree): boxes_sorted [N x 4] xyxy
+ * already in DESCENDING score order (class- or level-aware NMS: add idx * (max_coord + 1) to the
+ * coordinates first, as batched_nms does).  keep[0 .. *n_keep) receives the kept row indices in
+ * score order, at most max_keep of them; both are device pointers (keep: int64[max_keep]).  N <= 65536.
+ * ------------------------------------------------------------------------ */
+size_t repre_nms_workspace_bytes(int n_boxes);
+int repre_nms(const float* boxes_sorted, int n_boxes, float iou_thr, int max_keep, long long* keep,
+              int* n_keep, void* workspace, size_t workspace_bytes, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

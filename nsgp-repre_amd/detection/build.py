@@ -1,0 +1,40 @@
+"""Builders: the reference's VOC/COCO Faster R-CNN (cl_faster_rcnn_nsgp_repre_15_5_2.py) out of the stand-alone
+parts + the registered fork classes, and synthetic batches of the shape SURVEY 8(d) names."""
+import torch
+
+from .backbone import FPN, ResNet
+from .rpn_head import RPNHead
+from .structures import DetSample, Instances
+
+
+def build_faster_rcnn(depth=50, num_classes=20, task_id=1, task_split=(0, 15, 20), previous_path=None, max_prototype=10,
+                      rr_thresh=(0.5, 0.7), width=64, fc_out_channels=1024):
+    """``FasterRCNNRoIReplay`` with ``StandardMultiPrototypeReplayHead`` + ``Shared2FCBBoxHeadTask`` -- the model
+    dict of the reference's incremental configs.  ``width`` / ``fc_out_channels`` shrink it for CPU-side tests."""
+    from ..detectors import FasterRCNNRoIReplay
+    from ..roi_heads import Shared2FCBBoxHeadTask, StandardMultiPrototypeReplayHead
+    backbone = ResNet(depth, frozen_stages=1, norm_eval=True, width=width)
+    neck = FPN(backbone.out_channels, 256, 5)
+    head = Shared2FCBBoxHeadTask(in_channels=256, fc_out_channels=fc_out_channels, roi_feat_size=7, num_classes=num_classes,
+                                 task_split=task_split, task_id=task_id)
+    roi_head = StandardMultiPrototypeReplayHead(bbox_head=head, previous_path=previous_path, task_id=task_id,
+                                                task_split=task_split, max_prototype=max_prototype)
+    model = FasterRCNNRoIReplay(backbone=backbone, neck=neck, rpn_head=RPNHead(256, 256), roi_head=roi_head)
+    model.rpn_thresh, model.roi_thresh = rr_thresh                                      # runner:439-440
+    return model
+
+
+def synthetic_batch(batch_size, classes, device, height=800, width=1344, seed=0, min_boxes=3, max_boxes=8):
+    """``torch.rand(B,3,H,W)``-style pre-padded images + 3..8 boxes per image, labels uniform over ``classes``."""
+    g = torch.Generator().manual_seed(seed)
+    inputs = torch.rand(batch_size, 3, height, width, generator=g).to(device)
+    samples = []
+    lo, hi = classes
+    for _ in range(batch_size):
+        n = int(torch.randint(min_boxes, max_boxes + 1, (1,), generator=g))
+        wh = torch.rand(n, 2, generator=g) * torch.tensor([width * 0.4, height * 0.4]) + 32
+        xy = torch.rand(n, 2, generator=g) * (torch.tensor([width, height]) - wh)
+        boxes = torch.cat([xy, xy + wh], dim=-1)
+        labels = torch.randint(lo, hi, (n,), generator=g)
+        samples.append(DetSample(Instances(bboxes=boxes.to(device), labels=labels.to(device)), img_shape=(height, width)))
+    return inputs, samples

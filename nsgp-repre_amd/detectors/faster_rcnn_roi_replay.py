@@ -1,11 +1,11 @@
 """``FasterRCNNRoIReplay`` -- the detector-side boundary of the hot path
 (mmdet/models/detectors/faster_rcnn_roi_replay.py:14, forward :189-236).
 
-Only the mode dispatch belongs to the path: ``mode='nullspace'`` (a loss pass without the
-teacher, used under the covariance hooks by ``cal_fea_in``) and ``mode='roi_replay'`` (the RoI
-feature dump used by ``cal_rois``).  The detector forward/backward itself is stock PyTorch-ROCm
-(north_star), and the teacher pseudo-labelling inside ``loss`` (det:65-109) is SURVEY 8f-2
-("next"), not built this round: ``loss`` here runs the stock two-stage loss.
+The fork's own parts: the mode dispatch (``mode='nullspace'``: a loss pass without the teacher, used
+under the covariance hooks by ``cal_fea_in``; ``mode='roi_replay'``: the RoI feature dump used by
+``cal_rois``) and the teacher pseudo-labelling at the top of ``loss`` (det:65-109), whose
+per-box Python loop is one kernel here.  The detector forward/backward itself is stock PyTorch-ROCm
+(north_star): mmdet's ``TwoStageDetector`` when it is installed, ``nsgp_repre_amd.detection`` otherwise.
 """
 import torch.nn as nn
 
@@ -60,11 +60,30 @@ class FasterRCNNRoIReplay(RoIReplayModes, _Base):
             nn.Module.__init__(self)
             for k, v in kwargs.items():      # stand-alone: sub-modules are passed in ready-built
                 setattr(self, k, v)
-        self.rpn_thresh, self.roi_thresh = 0.5, 0.5   # set by the runner from rr_thresh (runner:439-440)
+        self.rpn_thresh, self.roi_thresh = 0.5, 0.7   # det:39-40; the runner overwrites them from rr_thresh (runner:439-440)
 
-    def pseudo_labelled_samples(self, batch_inputs, batch_data_samples):  # pragma: no cover - needs mmdet structures
-        """det:65-109: teacher predictions -> (rpn_data_samples, batch_data_samples) with the accepted
-        pseudo boxes appended; the per-box loop is the fused filter above."""
+    # -- the stock TwoStageDetector pieces, for the stand-alone build (mmdet provides them otherwise) ----------
+    if not _HAVE_MMDET:
+        with_rpn = True
+
+        def extract_feat(self, batch_inputs):
+            return self.neck(self.backbone(batch_inputs))
+
+        def predict(self, batch_inputs, batch_data_samples, rescale=True):
+            x = self.extract_feat(batch_inputs)
+            proposals = self.rpn_head.predict(x, batch_data_samples, rescale=False)
+            preds = self.roi_head.predict(x, proposals, batch_data_samples, rescale=rescale)
+            for sample, p in zip(batch_data_samples, preds):
+                sample.pred_instances = p
+            return batch_data_samples
+
+        def _forward(self, batch_inputs, batch_data_samples=None):
+            x = self.extract_feat(batch_inputs)
+            return self.rpn_head(x)
+
+    def pseudo_labelled_samples(self, batch_inputs, batch_data_samples):
+        """det:65-109: teacher predictions -> (rpn_data_samples, batch_data_samples) with the accepted pseudo
+        boxes appended.  The per-box Python loop (one ``.item()`` per box) is the fused filter above."""
         import copy
         import torch
         with torch.no_grad():
@@ -84,6 +103,28 @@ class FasterRCNNRoIReplay(RoIReplayModes, _Base):
         return rpn_samples, batch_data_samples
 
     def loss(self, batch_inputs, batch_data_samples, use_teacher_student=True):
-        if not _HAVE_MMDET:
-            raise RuntimeError("the stock two-stage loss needs mmdet")
-        return _Base.loss(self, batch_inputs, batch_data_samples)  # pragma: no cover
+        """det:44-142: features; teacher pseudo-labels (task >= 2, unless ``mode='nullspace'``); RPN loss on the
+        RPN set with labels zeroed; RoI-head loss (stock + replay) on the RoI set."""
+        import copy
+        import torch
+        x = self.extract_feat(batch_inputs)
+        rpn_data_samples = None
+        if hasattr(self, "teacher_model") and use_teacher_student:
+            rpn_data_samples, batch_data_samples = self.pseudo_labelled_samples(batch_inputs, batch_data_samples)
+        losses = dict()
+        if self.with_rpn:
+            train_cfg = getattr(self, "train_cfg", None)
+            proposal_cfg = train_cfg.get("rpn_proposal", self.test_cfg.rpn) if train_cfg is not None else None
+            rpn_data_samples = rpn_data_samples if rpn_data_samples else copy.deepcopy(batch_data_samples)
+            for data_sample in rpn_data_samples:                                   # class-agnostic RPN targets
+                data_sample.gt_instances.labels = torch.zeros_like(data_sample.gt_instances.labels)
+            rpn_losses, rpn_results_list = self.rpn_head.loss_and_predict(x, rpn_data_samples, proposal_cfg=proposal_cfg)
+            for key in list(rpn_losses.keys()):
+                if "loss" in key and "rpn" not in key:
+                    rpn_losses[f"rpn_{key}"] = rpn_losses.pop(key)
+            losses.update(rpn_losses)
+        else:
+            assert batch_data_samples[0].get("proposals", None) is not None
+            rpn_results_list = [data_sample.proposals for data_sample in batch_data_samples]
+        losses.update(self.roi_head.loss(x, rpn_results_list, batch_data_samples))
+        return losses

@@ -189,6 +189,29 @@ def pseudo_label_filter(boxes: torch.Tensor, scores: torch.Tensor, gt_boxes: tor
     return add_rpn.bool(), add_roi.bool()
 
 
+def nms(boxes: torch.Tensor, scores: torch.Tensor, iou_thr: float, idxs: torch.Tensor = None, max_keep: int = None):
+    """Greedy NMS -> kept indices into ``boxes`` in descending score order (mmcv.ops.nms / batched_nms, which
+    the teacher's per-step ``predict`` of det:72-74 calls).  ``idxs`` makes it class-/level-aware the way
+    batched_nms does: boxes of different groups are shifted apart so they never overlap."""
+    lib = _lib.load_library()
+    n = boxes.shape[0]
+    if n == 0:
+        return torch.empty(0, dtype=torch.int64, device=boxes.device)
+    order = torch.sort(scores, descending=True, stable=True).indices
+    b = boxes.float()
+    if idxs is not None:
+        b = b + (idxs.to(b) * (b.max() + 1))[:, None]
+    b = b[order].contiguous()
+    max_keep = n if max_keep is None else min(int(max_keep), n)
+    keep = torch.empty(max_keep, dtype=torch.int64, device=boxes.device)
+    n_keep = torch.empty(1, dtype=torch.int32, device=boxes.device)
+    nbytes = lib.repre_nms_workspace_bytes(n)
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=boxes.device)
+    _lib.check(lib.repre_nms(_dev(b, "boxes"), n, float(iou_thr), max_keep, _dev(keep, "keep", torch.int64),
+                             _dev(n_keep, "n_keep", torch.int32), C.c_void_p(ws.data_ptr()), nbytes, _stream()), "repre_nms")
+    return order[keep[:int(n_keep.item())]]
+
+
 def unpack_bitmask_row(words: torch.Tensor, n: int) -> torch.Tensor:
     """int64 words (little-endian bit order) -> bool[n] (host-side glue for mask.pth)."""
     w = words.cpu().numpy().view("uint64")

@@ -4,9 +4,9 @@ mmdet/models/roi_heads/standard_roi_replay_head.py (``StandardRoIReplayHead`` :3
 
 ``PrototypeReplay`` carries the fork's own logic (bank construction at start of task t, the
 per-step replay loss) against any object that has a ``bbox_head``; when mmdet is importable the
-registered head classes also inherit ``StandardRoIHead`` so the reference configs build them
-unchanged, and without mmdet they are plain ``nn.Module`` containers with the same constructor
-keywords.
+registered head classes inherit its ``StandardRoIHead`` so the reference configs build them
+unchanged; without mmdet they inherit ``detection.StandaloneRoIHead`` (the same stock recipe in plain
+PyTorch) and take the same constructor keywords.
 """
 import os.path as osp
 from typing import Optional, Sequence
@@ -24,7 +24,7 @@ try:  # pragma: no cover - mmdet is absent in this image
     from mmdet.models.roi_heads.standard_roi_head import StandardRoIHead as _Base
     _HAVE_MMDET = True
 except Exception:
-    _Base = nn.Module
+    from ..detection.roi_parts import StandaloneRoIHead as _Base     # the same recipe in plain torch
     _HAVE_MMDET = False
 
 
@@ -92,7 +92,10 @@ class PrototypeReplay:
     def add_replay_loss(self, losses: dict) -> dict:
         """The tail of ``loss`` (head:454-466): stock RoI losses + ``replay_loss_cls``."""
         if self.replay:
-            losses.update(self.replay_loss(self.bbox_featss)["replay_loss"])
+            # the bank pass stays fp32 under an autocast training step (>= the reference's precision; the
+            # bf16 path of this K x 12544 x 1024 GEMM measured 7x slower on hipBLASLt)
+            with torch.autocast(device_type=self.bbox_featss.device.type, enabled=False):
+                losses.update(self.replay_loss(self.bbox_featss)["replay_loss"])
         return losses
 
 
@@ -103,10 +106,7 @@ def _init_base(self, bbox_roi_extractor, bbox_head, mask_roi_extractor, mask_hea
                        test_cfg, init_cfg)
     else:
         nn.Module.__init__(self)
-        if isinstance(bbox_head, dict):
-            bbox_head = MODELS.build(bbox_head)
-        self.bbox_head = bbox_head
-        self.train_cfg, self.test_cfg = train_cfg, test_cfg
+        self.init_standalone(bbox_roi_extractor, bbox_head, train_cfg, test_cfg)
 
 
 @register(MODELS)
@@ -174,6 +174,5 @@ class StandardMultiPrototypeReplayHead(PrototypeReplay, RoIDump, _Base):
         self.init_prototype_replay(previous_path, task_id, task_split, max_prototype)
 
     def loss(self, x, rpn_results_list, batch_data_samples) -> dict:
-        if not _HAVE_MMDET:
-            raise RuntimeError("the stock RoI loss needs mmdet; the replay part is `add_replay_loss`")
-        return self.add_replay_loss(_Base.loss(self, x, rpn_results_list, batch_data_samples))  # pragma: no cover
+        """head:454-466: the stock RoI losses, then ``replay_loss_cls`` from the bank."""
+        return self.add_replay_loss(_Base.loss(self, x, rpn_results_list, batch_data_samples))

@@ -31,10 +31,17 @@ def select_five_rois(cls_target: torch.Tensor, bg_class_id: int, target_count: i
 
 
 class RoIDump:
-    """``get_bbox_stuff`` for heads that inherit mmdet's ``StandardRoIHead`` (needs its assigner,
-    sampler, RoI extractor and ``bbox_head.get_roi_targets``)."""
+    """``get_bbox_stuff`` over the stock assigner / sampler / RoI extractor / ``get_roi_targets`` of whichever
+    ``StandardRoIHead`` the head inherits (mmdet's, or ``detection.StandaloneRoIHead``)."""
 
-    def get_bbox_stuff(self, x, rpn_results_list, batch_data_samples, extract_gt=False):  # pragma: no cover - needs mmdet
+    def get_bbox_stuff(self, x, rpn_results_list, batch_data_samples, extract_gt=False):
+        if hasattr(self, "sampled_roi_stuff"):       # stand-alone head (detection.StandaloneRoIHead): same stock half
+            bbox_feats, cls_t, cls_w, box_t, box_w, rois = self.sampled_roi_stuff(x, rpn_results_list, batch_data_samples)
+            mask = select_five_rois(cls_t, self.bbox_head.num_classes)
+            return bbox_feats[mask], cls_t[mask], cls_w[mask], box_t[mask], box_w[mask], rois[mask]
+        return self._get_bbox_stuff_mmdet(x, rpn_results_list, batch_data_samples)
+
+    def _get_bbox_stuff_mmdet(self, x, rpn_results_list, batch_data_samples):  # pragma: no cover - needs mmdet
         from mmdet.models.utils import unpack_gt_instances
         from mmdet.structures.bbox import bbox2roi
         assert len(rpn_results_list) == len(batch_data_samples)

@@ -10,8 +10,8 @@ Two faces of one class name:
 * without MMEngine (this image) it is a small stand-alone driver over plain torch objects with the
   same method names, which is what the tests exercise.
 
-Both delegate every NSGP/RePRE step to ``runner/nullspace.py``.  Out of scope here:
-the EWC regulariser and the teacher pseudo-labelling.
+Both delegate every NSGP/RePRE step to ``runner/nullspace.py``; the EWC regulariser lives in
+``runner/ewc.py``.
 """
 import os.path as osp
 from typing import Callable, Iterable, Optional, Sequence
@@ -53,6 +53,21 @@ class NullSpaceTaskMixin:
         dev = next(NS.unwrap(model).parameters()).device
         return NS.update_optim_transforms(optimizer, self.fea_in_load_path, self.ignore_keys, self.offset, dev)
 
+    def attach_teacher(self, model):
+        """runner:527-547: a frozen deep copy of the (checkpoint-loaded) model answers for the old tasks -- its
+        head is switched to task ``t-1`` -- and the RoI head gets a handle on the teacher's RoI head."""
+        import copy
+        ori = NS.unwrap(model)
+        if hasattr(ori, "teacher_model"):
+            del ori.teacher_model
+        ori.teacher_model = copy.deepcopy(ori)
+        ori.teacher_model.roi_head.bbox_head.task_id = self.task_id - 1
+        ori.roi_head.teacher_model = ori.teacher_model.roi_head
+        for name, param in ori.named_parameters():
+            if "teacher" in name:
+                param.requires_grad_(False)
+        return ori.teacher_model
+
     # -- end of task t --------------------------------------------------------------------------
     def cal_fea_in(self, model, batches: Iterable, forward: Optional[Callable] = None):
         return NS.cal_fea_in(model, batches, self.ignore_keys, self.fea_in_save_path,
@@ -92,6 +107,8 @@ if HAVE_MMENGINE:  # pragma: no cover - exercised only where mmengine is install
             self._init_model_weights()
             self.load_or_resume()
             if self.task_id != 1 and not self.is_trained:
+                if "joint" not in self.work_dir:
+                    self.attach_teacher(self.model)
                 assert self._resume is False                                                          # runner:551
                 NullSpaceTaskMixin.update_optim_transforms(self, self.optim_wrapper.optimizer, model)
             self.optim_wrapper.initialize_count_status(self.model, self._train_loop.iter, self._train_loop.max_iters)
@@ -126,6 +143,9 @@ else:
 
         def train(self, step_fn: Callable, batches: Iterable, cov_forward: Optional[Callable] = None,
                   cov_batches: Optional[Iterable] = None, roi_forward: Optional[Callable] = None):
+            if (self.task_id != 1 and not self.is_trained and "joint" not in self.work_dir
+                    and hasattr(NS.unwrap(self.model), "roi_head")):
+                self.attach_teacher(self.model)
             self.wire_param_names(self.optimizer, self.model)
             if self.task_id != 1 and not self.is_trained:
                 self.update_optim_transforms(self.optimizer, self.model)

@@ -489,6 +489,29 @@ def pseudo_label_filter(boxes: torch.Tensor, scores: torch.Tensor, gt: torch.Ten
     return add_rpn, add_roi
 
 
+def nms_greedy(boxes: torch.Tensor, scores: torch.Tensor, iou_thresh: float, idxs: torch.Tensor = None,
+               max_keep: int = None) -> torch.Tensor:
+    """mmcv.ops.nms / batched_nms as the teacher's ``predict`` uses them (faster_rcnn_roi_replay.py:72-74).
+    mmcv (>=2.0.0rc4,<2.2.0) is not vendored in the reference tree; this is the published greedy algorithm:
+    descending (stable) score order, a box is kept unless IoU with an already kept box > thr; batched = boxes
+    of different groups shifted apart by ``idx * (max coordinate + 1)``.  Parity unpinned by reference
+    fixtures (the reference holds none for NMS)."""
+    if len(boxes) == 0:
+        return torch.zeros(0, dtype=torch.int64)
+    b = boxes.float().cpu()
+    if idxs is not None:
+        b = b + (idxs.cpu().to(b) * (b.max() + 1))[:, None]
+    order = torch.sort(scores.cpu(), descending=True, stable=True).indices
+    kept = []
+    for i in order.tolist():
+        if kept and (box_iou(b[i:i + 1], b[kept]) > iou_thresh).any():
+            continue
+        kept.append(i)
+        if max_keep is not None and len(kept) >= max_keep:
+            break
+    return torch.tensor(kept, dtype=torch.int64)
+
+
 # ----------------------------------------------------------------------------
 # C1 / C2 collectives, stated as plain list-of-ranks arithmetic
 # ----------------------------------------------------------------------------
