@@ -194,12 +194,110 @@ def cpu_baseline(table, seconds_budget=15.0):
                        "included on the CPU side (that favours the CPU number)")
 
 
+def end_to_end_training(N, dev, world, local_rank, basis_cache, steps, warmup, amp, batch_size=1, channels_last=False):
+    """SURVEY 8(d) "end-to-end img/s": the whole task-2 training step of cl_faster_rcnn_nsgp_repre_15_5_2.py on synthetic
+    800x1344 batches -- teacher predict + pseudo-label filter, student forward (RPN + RoI losses + replay loss on the
+    K=150 bank), backward (DDP bucketed RCCL all-reduce overlapped with it when world > 1) and the projected SGDNSCL
+    step.  The detector is nsgp_repre_amd.detection (stock recipe in plain PyTorch-ROCm; mmdet is not in the image)."""
+    import copy
+    import torch.distributed as dist
+    from nsgp_repre_amd.detection import build_faster_rcnn, synthetic_batch
+    torch.manual_seed(4321)
+    model = build_faster_rcnn(depth=50, num_classes=20, task_id=2, task_split=[0, 15, 20]).to(dev)
+    head = model.roi_head
+    head.replay, K = True, 150
+    head.bbox_featss = torch.relu(torch.randn(K, 12544, device=dev))
+    head.tmp_label = torch.randint(0, 15, (K,), device=dev)
+    mix = N.runner.br_nullspace_runner.NullSpaceTaskMixin()
+    mix.task_id = 2
+    mix.attach_teacher(model)                                  # runner:527-547
+    opt = N.SGDNSCL(model.parameters(), lr=0.02, momentum=0.9, weight_decay=1e-4, svd=True)
+    N.runner.nullspace.wire_param_names(opt, model)             # runner:473-484
+    ignore = N.runner.nullspace.full_ignore_keys(["rpn", "roi_head"])
+    n_proj = 0
+    for n, p in model.named_parameters():
+        if p.requires_grad and p.dim() == 4 and not N.runner.nullspace.should_ignore(n, ignore):
+            D = p[0].numel()
+            if D not in basis_cache:
+                basis_cache[D] = make_basis(D, dev, 2000 + D)
+            opt.set_basis(n, basis_cache[D][0], basis_cache[D][1])
+            n_proj += 1
+    model.train()
+    # channels_last: only the ACTIVATIONS (the input image decides the layout of every convolution's output);
+    # parameters stay contiguous -- the optimizer's [Cout x D] view of a conv weight is the reference's layout
+    net = model
+    if world > 1:
+        net = torch.nn.parallel.DistributedDataParallel(model, device_ids=[local_rank], broadcast_buffers=False,
+                                                        gradient_as_bucket_view=True)
+    batches = [synthetic_batch(batch_size, (15, 20), dev, seed=100 * local_rank + i) for i in range(4)]
+    if channels_last:
+        batches = [(x.contiguous(memory_format=torch.channels_last), s) for x, s in batches]
+    fwd_bwd, opt_ms = [], []
+
+    def one_step(i):
+        x, samples = batches[i % len(batches)]
+        e0, e1, e2 = (torch.cuda.Event(enable_timing=True) for _ in range(3))
+        e0.record()
+        with torch.autocast("cuda", dtype=torch.bfloat16, enabled=amp):
+            losses = net(x, copy.deepcopy(samples), mode="loss")
+        loss = sum(v for k, v in losses.items() if "loss" in k)
+        loss.backward()
+        e1.record()
+        opt.step()
+        opt.zero_grad()
+        e2.record()
+        return losses, (e0, e1, e2)
+
+    for i in range(warmup):
+        losses, _ = one_step(i)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    opt.profile_begin(steps)
+    t0 = time.perf_counter()
+    evs = []
+    for i in range(steps):
+        losses, ev = one_step(i)
+        evs.append(ev)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = t.item()
+    n_prof, update_ms, gemm_ms = opt.profile_end()
+    for e0, e1, e2 in evs:
+        fwd_bwd.append(e0.elapsed_time(e1))
+        opt_ms.append(e1.elapsed_time(e2))
+    finite = all(bool(torch.isfinite(v)) for v in losses.values())
+    out = {"img_s": world * batch_size * steps / elapsed, "ms_per_step": elapsed / steps * 1e3, "steps": steps, "warmup": warmup,
+           "batch_per_gpu": batch_size, "memory_format": "channels_last" if channels_last else "contiguous (NCHW)", "image": "3x800x1344 (1333x800 padded to /32)", "n_gpus": world,
+           "teacher_student_fwd_bwd_ms": sum(fwd_bwd) / len(fwd_bwd), "optimizer_step_ms": sum(opt_ms) / len(opt_ms),
+           "nsgp_kernels_ms": update_ms + gemm_ms, "projected_layers": n_proj,
+           "trainable_tensors": sum(len(g["params"]) for g in opt.param_groups),
+           "losses_finite": finite, "loss_keys": sorted(losses.keys()),
+           "detector_dtype": "bf16 autocast (replay-bank pass, losses, NSGP step fp32)" if amp else "f32",
+           "parallelism": f"DDP x{world}: bucketed RCCL all-reduce of the gradients overlapped with backward" if world > 1 else "single",
+           "detector": "nsgp_repre_amd.detection (R-50-FPN Faster R-CNN, stock recipe in plain PyTorch-ROCm: MIOpen convolutions, "
+                       "hipBLASLt GEMMs; teacher predict + pseudo-label filter every step, as det:65-109)"}
+    del net, model, opt
+    torch.cuda.empty_cache()
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=30)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-end-to-end", action="store_true", help="skip the end-to-end training img/s section")
+    ap.add_argument("--e2e-steps", type=int, default=20)
+    ap.add_argument("--e2e-f32", action="store_true", help="run the detector of the end-to-end section in fp32 instead of bf16 autocast")
     ap.add_argument("--amp", action="store_true", help="run the replay head's GEMMs under bf16 autocast (measured 7x SLOWER "
                     "than fp32 on this image's hipBLASLt for the M=150 shapes: 12.4 vs 1.66 ms per step, so off by default)")
     args = ap.parse_args()
@@ -307,6 +405,9 @@ def main():
             dist.all_reduce(flat_grads)
         torch.cuda.synchronize()
         allreduce_ms = (time.perf_counter() - t_ar) / 10 * 1e3
+    e2e = None
+    if not args.no_end_to_end:      # every rank takes part (DDP); the hot-path numbers above are already in the bag
+        e2e = end_to_end_training(N, dev, world, local_rank, cache, args.e2e_steps, 3, not args.e2e_f32)
     if rank == 0:
         flops, abytes, ntiles, nproj = opt.plan_stats()
         # dominant kernel = the grouped projection GEMM: HIP events recorded by the library around
@@ -357,6 +458,8 @@ def main():
                                    "achieved_tflops": lr_flops / (lr_gemm_ms * 1e-3) / 1e12, "tiles_phase1": lt1, "tiles_phase2": lt2,
                                    "synthetic_rank": "r = D/16", "note": "opt-in (optimizer.low_rank=True); parity vs the dense form: tests/test_gpu_parity.py::test_low_rank_form_matches_dense_form"}
             opt.low_rank = False
+        if e2e is not None:
+            out["end_to_end"] = e2e
         if world == 1:
             out["once_per_task"] = once_per_task_units(dev)
         traffic_file = os.path.join(ROOT, "profiles", "r01_traffic.json")

@@ -63,7 +63,7 @@ class RoIAlignExtractor(nn.Module):
 
     def forward(self, feats, rois):
         k, n = rois.shape[0], self.out * self.s
-        out = feats[0].new_zeros(k, feats[0].shape[1], self.out, self.out)
+        out = feats[0].new_zeros(k, feats[0].shape[1], self.out, self.out, dtype=torch.float32)
         if k == 0:
             return out
         lvls = self.map_levels(rois)
@@ -73,7 +73,7 @@ class RoIAlignExtractor(nn.Module):
             if idx.numel() == 0:
                 continue
             r = rois[idx]
-            f = feats[l]
+            f = feats[l].float()        # fp32 sampling under autocast too: the bf16 grid_sample backward (atomics) is 4x slower
             H, W = f.shape[2:]
             x1, y1 = r[:, 1] / stride - 0.5, r[:, 2] / stride - 0.5
             bw, bh = (r[:, 3] - r[:, 1]) / stride, (r[:, 4] - r[:, 2]) / stride
