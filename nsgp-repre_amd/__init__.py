@@ -11,6 +11,6 @@ point raises if the HIP library is missing or the tensors are not on a GPU.
 from . import registry  # noqa: F401
 from ._lib import lib_path, load_library  # noqa: F401
 from .optim import AdamNSCL, AdamWNSCL, SGDNSCL, SGDNSCLNA  # noqa: F401
-from . import detectors, roi_heads, runner  # noqa: F401,E402
+from . import datasets, detectors, roi_heads, runner  # noqa: F401,E402
 
 __version__ = "0.1.0"

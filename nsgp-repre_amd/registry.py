@@ -40,17 +40,21 @@ class _LocalRegistry:
 
 try:  # pragma: no cover - mmengine is absent in this image
     from mmengine.registry import MODELS, OPTIMIZERS, RUNNERS
+    DATASETS = None     # the fork's own host-only dataset classes stay in charge (see datasets/__init__.py)
     HAVE_MMENGINE = True
 except Exception:
     OPTIMIZERS = _LocalRegistry("optimizer")
     RUNNERS = _LocalRegistry("runner")
     MODELS = _LocalRegistry("model")
+    DATASETS = _LocalRegistry("dataset")
     HAVE_MMENGINE = False
 
 
 def register(registry, name=None):
     """``force=True`` so that re-registering over the reference fork's own class works."""
     def deco(cls):
+        if registry is None:
+            return cls
         try:
             registry.register_module(name=name or cls.__name__, force=True, module=cls)
         except TypeError:

@@ -200,3 +200,58 @@ def g6_tensors():
         old = [(theta[None] + 0.1 * rng.standard_normal((1,) + shp)).astype(np.float32) for _ in range(G6_TASKS)]
         out[n] = (theta, imp, old)
     return out
+
+
+# ----------------------------------------------------------------------------
+# G7: task-split annotation parsing (xml_style_task.py / coco_task.py)
+# ----------------------------------------------------------------------------
+G7_VOC = ("aeroplane", "bicycle", "bird", "boat", "bottle", "bus", "car", "cat", "chair", "cow", "diningtable", "dog",
+          "horse", "motorbike", "person", "pottedplant", "sheep", "sofa", "train", "tvmonitor")
+G7_SPLITS = [([0, 15, 20], 1), ([0, 15, 20], 2), ([0, 10, 20], 2), ([0, 5, 10, 15, 20], 3), ([0, 19, 20], 2)]
+
+
+def g7_xml_docs(n_docs=12):
+    """VOC-style XML strings: 0-6 objects, some unknown class names, difficult flags, boxes below bbox_min_size,
+    float-formatted coordinates, one document without <difficult> tags."""
+    rng = np.random.default_rng(700)
+    docs = []
+    for d in range(n_docs):
+        w, h = int(rng.integers(200, 600)), int(rng.integers(200, 600))
+        objs = []
+        for k in range(int(rng.integers(0, 7))):
+            name = "zebra" if rng.random() < 0.1 else G7_VOC[int(rng.integers(0, 20))]
+            x1, y1 = int(rng.integers(1, w - 60)), int(rng.integers(1, h - 60))
+            bw, bh = (int(rng.integers(1, 5)), int(rng.integers(1, 60))) if rng.random() < 0.2 else (int(rng.integers(5, 60)), int(rng.integers(5, 60)))
+            fmt = (lambda v: f"{v}.0") if rng.random() < 0.3 else str
+            diff = "" if d == 3 else f"<difficult>{int(rng.random() < 0.25)}</difficult>"
+            objs.append(f"<object><name>{name}</name>{diff}<bndbox><xmin>{fmt(x1)}</xmin><ymin>{fmt(y1)}</ymin>"
+                        f"<xmax>{fmt(x1 + bw)}</xmax><ymax>{fmt(y1 + bh)}</ymax></bndbox></object>")
+        docs.append(f"<annotation><filename>{d:06d}.jpg</filename><size><width>{w}</width><height>{h}</height><depth>3</depth></size>"
+                    + "".join(objs) + "</annotation>")
+    return docs
+
+
+def g7_coco():
+    """A COCO-style dict: 12 categories with non-contiguous ids (two of them outside `classes`), 10 images,
+    annotations incl. crowd, zero-area, out-of-image, ignore and sub-pixel boxes."""
+    rng = np.random.default_rng(701)
+    names = ["person", "bicycle", "car", "unicorn", "motorcycle", "airplane", "bus", "train", "dragon", "truck", "boat", "traffic light"]
+    cats = [dict(id=3 * i + 1, name=n) for i, n in enumerate(names)]
+    images = [dict(id=100 + i, file_name=f"{i:012d}.jpg", width=int(rng.integers(100, 640)), height=int(rng.integers(20, 480))) for i in range(10)]
+    anns, aid = [], 1
+    for img in images[:-1]:                      # the last image has no annotation at all
+        for _ in range(int(rng.integers(1, 6))):
+            c = cats[int(rng.integers(0, len(cats)))]
+            x, y = float(rng.uniform(-20, img["width"] - 5)), float(rng.uniform(-20, img["height"] - 5))
+            w, h = float(rng.uniform(0.5, 120)), float(rng.uniform(0.5, 120))
+            a = dict(id=aid, image_id=img["id"], category_id=c["id"], bbox=[round(x, 2), round(y, 2), round(w, 2), round(h, 2)],
+                     area=0.0 if rng.random() < 0.1 else round(w * h, 2), iscrowd=int(rng.random() < 0.15))
+            if rng.random() < 0.1:
+                a["ignore"] = True
+            anns.append(a)
+            aid += 1
+    return dict(images=images, annotations=anns, categories=cats)
+
+
+G7_COCO_CLASSES = ("person", "bicycle", "car", "motorcycle", "airplane", "bus", "train", "truck", "boat", "traffic light")
+G7_COCO_SPLITS = [([0, 5, 10], 1), ([0, 5, 10], 2), ([0, 4, 8, 10], 3)]

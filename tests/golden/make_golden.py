@@ -241,6 +241,50 @@ def run_ewc():
     save("g6_ewc.npz", **out)
 
 
+def run_task_split():
+    """G7: the fork's task-split annotation rules, run through its own dataset classes (unbound methods on a
+    namespace carrying exactly the attributes they read).  Stored as JSON."""
+    import json
+    import types
+    import xml.etree.ElementTree as ET
+    ref_xml = R.load("mmdet/datasets/xml_style_task.py")
+    ref_coco = R.load("mmdet/datasets/coco_task.py")
+    out = {"xml": [], "coco": []}
+    docs = I.g7_xml_docs()
+    for split, task_id in I.G7_SPLITS:
+        for min_size in (None, 5):
+            ns = types.SimpleNamespace(_metainfo={"classes": I.G7_VOC}, cat2label={c: i for i, c in enumerate(I.G7_VOC)},
+                                       bbox_min_size=min_size, test_mode=False, task_split=split, task_id=task_id)
+            per_doc = [ref_xml.XMLTask._parse_instance_info(ns, ET.ElementTree(ET.fromstring(d)), minus_one=True) for d in docs]
+            ns.data_list = [dict(width=int(ET.fromstring(d).find("size/width").text), height=int(ET.fromstring(d).find("size/height").text),
+                                 instances=inst, img_id=i) for i, (d, inst) in enumerate(zip(docs, per_doc)) if len(inst) != 0]
+            ns.filter_cfg = dict(filter_empty_gt=True, min_size=250, bbox_min_size=min_size)
+            kept = [d["img_id"] for d in ref_xml.XMLTask.filter_data(ns)]
+            out["xml"].append(dict(task_split=split, task_id=task_id, bbox_min_size=min_size, instances=per_doc, kept_after_filter=kept))
+    coco = I.g7_coco()
+    cat_ids = [c["id"] for c in coco["categories"] if c["name"] in I.G7_COCO_CLASSES]      # COCO.get_cat_ids(cat_names=...)
+    anns = {}
+    cat_img_map = {cid: [] for cid in [c["id"] for c in coco["categories"]]}
+    for a in coco["annotations"]:
+        anns.setdefault(a["image_id"], []).append(a)
+        cat_img_map[a["category_id"]].append(a["image_id"])
+    for split, task_id in I.G7_COCO_SPLITS:
+        ns = types.SimpleNamespace(data_prefix={"img": "imgs/"}, seg_map_suffix=".png", return_classes=False, test_mode=False,
+                                   cat2label={cid: i for i, cid in enumerate(cat_ids)}, cat_img_map=cat_img_map,
+                                   keep_cat=[cat_ids[i] for i in range(split[task_id - 1], split[task_id])])
+        ns.data_list = []
+        for img in coco["images"]:
+            raw = dict(img)
+            raw["img_id"] = img["id"]
+            ns.data_list.append(ref_coco.CocoTaskDataset.parse_data_info(ns, dict(raw_ann_info=anns.get(img["id"], []), raw_img_info=raw)))
+        ns.filter_cfg = dict(filter_empty_gt=True, min_size=32)
+        kept = [d["img_id"] for d in ref_coco.CocoTaskDataset.filter_data(ns)]
+        out["coco"].append(dict(task_split=split, task_id=task_id, data_list=ns.data_list, kept_after_filter=kept))
+    path = os.path.join(HERE, "g7_task_split.json")
+    json.dump(out, open(path, "w"))
+    print(f"g7_task_split.json: {os.path.getsize(path) / 1024:.1f} KiB")
+
+
 if __name__ == "__main__":
     for kind in ("sgd", "sgd_nesterov", "adamw", "adamw_amsgrad", "adam", "sgdna"):
         run_optimizer(kind)
@@ -249,3 +293,4 @@ if __name__ == "__main__":
     run_prototypes()
     run_replay_loss()
     run_ewc()
+    run_task_split()
