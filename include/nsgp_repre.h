@@ -141,7 +141,7 @@ int nsgp_project(const float* a, const float* proj, float* out, int rows, int co
  *   mmdet/engine/runner/nsrunner_roi_replay.py:876-916, 923-934:
  *   X = unfold(mean_batch(x), k, pad, stride) viewed [L x D];  C (+)= X^T X
  * without materialising X (implicit im2col).  x: [B,Cin,H,W]; cov: [D x D], D=Cin*kh*kw.
- * workspace: >= nsgp_cov_workspace_bytes (the zero-padded batch mean + the split-L partial tiles).
+ * workspace: >= nsgp_cov_workspace_bytes (the zero-padded batch mean + one 128x128 slab per stream-K segment).
  * accumulate=0 is the reference's first call (assign), 1 the later ones (add).
  * ------------------------------------------------------------------------ */
 size_t nsgp_cov_workspace_bytes(int cin, int h, int w, int kh, int kw, int sh, int sw, int ph, int pw);

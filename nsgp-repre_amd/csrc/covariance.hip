@@ -7,10 +7,14 @@
 //      (so the gather needs no bounds tests);
 //   2. nsgp_cov_syrk_kernel        implicit-im2col SYRK on the fp32 MFMA core: both operands are
 //      "rows" images whose row d=(c,i,j) at column l=(oy,ox) is xm[c][oy*sh+i][ox*sw+j]; only the
-//      128x128 tiles on or above the diagonal are computed, the L dimension is split S ways so
-//      that even a D=64 layer fills the chip, each split writing its partial tile to workspace;
-//   3. nsgp_cov_reduce_kernel      C (=|+=) sum_s partial[s], mirrored into the lower triangle,
-//      in a fixed order (deterministic; no float atomics).
+//      128x128 tiles on or above the diagonal are computed.  Work is split stream-K style: the
+//      flattened (tile, K-step) space is cut into P equal contiguous ranges, one per resident
+//      workgroup (P <= 512 = 2 per CU), so every workgroup does the same number of K-steps whatever
+//      D and L are (equal-sized (tile, L-chunk) units left up to half the chip idle: 513 units for
+//      D=2304, 342 for the six layer3 3x3s).  A range covers the tail of one tile, whole tiles, and
+//      the head of another; each such segment writes its 128x128 partial to slab (tile + workgroup);
+//   3. nsgp_cov_reduce_kernel      per tile: C (=|+=) sum of its segments' slabs in workgroup order
+//      (deterministic; no float atomics), mirrored into the lower triangle through LDS.
 #include <algorithm>
 
 #include "common.hpp"
@@ -108,66 +112,106 @@ __device__ __forceinline__ void im2col_rowbase(const ConvGeom& g, int d0, long (
     }
 }
 
-__global__ __launch_bounds__(256, 2) void nsgp_cov_syrk_kernel(const float* __restrict__ xm, ConvGeom g, int l_chunk,
-                                                               float* __restrict__ partial) {
+// first flattened index of workgroup w's range, and the workgroup that owns flattened index gidx
+__host__ __device__ __forceinline__ long sk_begin(long w, long G, long P) { return w * G / P; }
+__host__ __device__ __forceinline__ long sk_owner(long gidx, long G, long P) { return ((gidx + 1) * P - 1) / G; }
+
+__device__ __forceinline__ void tile_of(int t, int nb, int& ti, int& tj) {
+    ti = 0;
+    int rem = t;
+    while (rem >= nb - ti) { rem -= nb - ti; ++ti; }
+    tj = ti + rem;
+}
+
+__global__ __launch_bounds__(256, 2) void nsgp_cov_syrk_kernel(const float* __restrict__ xm, ConvGeom g, int nk, long G,
+                                                               float* __restrict__ slabs) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int nb = (g.D + BM - 1) / BM;
-    int ti = 0, rem = blockIdx.x;
-    while (rem >= nb - ti) { rem -= nb - ti; ++ti; }
-    const int m0 = ti * BM, n0 = (ti + rem) * BN;
-    const int l_beg = blockIdx.y * l_chunk;
-    const int l_end = min(l_beg + l_chunk, g.L);
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int wm = wave >> 1, wn = wave & 1;
-    f32x16 acc[2][2];
-    zero_acc(acc);
-    long base_a[4], base_b[4];
-    im2col_rowbase(g, m0, base_a);
-    im2col_rowbase(g, n0, base_b);
-    float ra[2][4][4], rb[2][4][4];
+    const long P = gridDim.x, w = blockIdx.x;
+    long gi = sk_begin(w, G, P);
+    const long g_end = sk_begin(w + 1, G, P);
     const float inv_wo = 1.0f / (float)g.Wo;
-    mfma_pipeline<true>(
-        (l_end - l_beg + BK - 1) / BK, smem, acc,
-        [&](int t, auto s) {
-            const PatchCols pc = patch_cols(g, inv_wo, l_beg + t * BK, l_end);   // shared by both operands
-            stage_im2col(xm, base_a, pc, ra[decltype(s)::value]);
-            stage_im2col(xm, base_b, pc, rb[decltype(s)::value]);
-        },
-        [&](float* img, int, auto s) { write_rows(img, ra[decltype(s)::value]); },
-        [&](float* img, int, auto s) { write_rows(img, rb[decltype(s)::value]); });
-    float* out = partial + (long)blockIdx.y * g.D * g.D;
-    if (g.D % BM == 0) {   // full tiles: park the block in LDS, store float4 rows (short K chunks make the store matter)
+    float ra[2][4][4], rb[2][4][4];
+    while (gi < g_end) {                                       // uniform across the workgroup
+        const int t = (int)(gi / nk);
+        const int ja = (int)(gi - (long)t * nk);
+        const int jb = (int)min((long)nk, ja + (g_end - gi));
+        int ti, tj;
+        tile_of(t, nb, ti, tj);
+        const int m0 = ti * BM, n0 = tj * BN;
+        const int l_beg = ja * BK, l_end = min(jb * BK, g.L);
+        f32x16 acc[2][2];
+        zero_acc(acc);
+        long base_a[4], base_b[4];
+        im2col_rowbase(g, m0, base_a);
+        im2col_rowbase(g, n0, base_b);
+        mfma_pipeline<true>(
+            jb - ja, smem, acc,
+            [&](int step, auto s) {
+                const PatchCols pc = patch_cols(g, inv_wo, l_beg + step * BK, l_end);   // shared by both operands
+                stage_im2col(xm, base_a, pc, ra[decltype(s)::value]);
+                stage_im2col(xm, base_b, pc, rb[decltype(s)::value]);
+            },
+            [&](float* img, int, auto s) { write_rows(img, ra[decltype(s)::value]); },
+            [&](float* img, int, auto s) { write_rows(img, rb[decltype(s)::value]); });
+        // park the block in LDS and store float4 rows into this segment's slab (always a full 128x128: rows >= D are zero)
+        float* out = slabs + ((long)t + w) * (BM * BN);
         acc_to_lds(smem, acc);
         for_each_row4(smem, [&](int r, int col, float4 v) {
             f32x4 q;
             q[0] = v.x; q[1] = v.y; q[2] = v.z; q[3] = v.w;
-            *(gf32x4*)(out + (long)(m0 + r) * g.D + n0 + col) = q;
+            *(gf32x4*)(out + r * BN + col) = q;
         });
-        return;
+        __syncthreads();                                        // LDS is free again for the next segment's prologue
+        gi += jb - ja;
     }
-#pragma unroll
-    for (int mi = 0; mi < 2; ++mi)
-#pragma unroll
-        for (int ni = 0; ni < 2; ++ni) {
-            const int col = n0 + wn * 64 + ni * 32 + (lane & 31);
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int row = m0 + wm * 64 + mi * 32 + acc_row(r, lane);
-                if (row < g.D && col < g.D) as_global(out)[(long)row * g.D + col] = acc[mi][ni][r];
-            }
-        }
 }
 
-__global__ __launch_bounds__(256) void nsgp_cov_reduce_kernel(const float* __restrict__ partial, int S, int D,
-                                                              float* __restrict__ cov, int accumulate) {
-    const long n = (long)D * D;
-    for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < n; idx += (long)gridDim.x * 256) {
-        const int r = (int)(idx / D), c = (int)(idx - (long)r * D);
-        // the tile that holds (r,c) was computed iff its tile row <= tile column; else read the mirror
-        const long src = (r / BM <= c / BN) ? idx : ((long)c * D + r);
-        float s = partial[src];
-        for (int k = 1; k < S; ++k) s += partial[(long)k * n + src];
-        cov[idx] = accumulate ? (cov[idx] + s) : s;
+constexpr int RED_LD = BN + 1;
+constexpr int RED_MAX_ROWS = 64;
+
+// grid (tiles, R): workgroup (t, y) owns rows [y*rows, (y+1)*rows) of upper-triangle tile t: sums that band over
+// the tile's segments in workgroup order, writes it and its mirror.  R grows when there are few tiles -- a D=64
+// layer is ONE tile cut into 512 segments, and a single workgroup would stream all 32 MB of slabs by itself.
+__global__ __launch_bounds__(256) void nsgp_cov_reduce_kernel(const float* __restrict__ slabs, int D, int nk, long G, long P,
+                                                              int rows, float* __restrict__ cov, int accumulate) {
+    __shared__ float tile[RED_MAX_ROWS * RED_LD];
+    const int nb = (D + BM - 1) / BM;
+    const int t = blockIdx.x, r0 = blockIdx.y * rows;
+    int ti, tj;
+    tile_of(t, nb, ti, tj);
+    const int m0 = ti * BM, n0 = tj * BN;
+    if (m0 + r0 >= D) return;                                   // band entirely below the matrix edge
+    const long w_first = sk_owner((long)t * nk, G, P), w_last = sk_owner((long)(t + 1) * nk - 1, G, P);
+    for (int idx = threadIdx.x; idx < rows * BN / 4; idx += 256) {
+        const int r = idx / (BN / 4), c4 = (idx - r * (BN / 4)) * 4;
+        const long off = (long)(r0 + r) * BN + c4;
+        f32x4 sum = *(const gf32x4*)(slabs + ((long)t + w_first) * (BM * BN) + off);
+        for (long w = w_first + 1; w <= w_last; ++w) {
+            const f32x4 v = *(const gf32x4*)(slabs + ((long)t + w) * (BM * BN) + off);
+            sum[0] += v[0]; sum[1] += v[1]; sum[2] += v[2]; sum[3] += v[3];
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) tile[r * RED_LD + c4 + e] = sum[e];
+    }
+    __syncthreads();
+    for (int idx = threadIdx.x; idx < rows * BN; idx += 256) {
+        const int r = idx >> 7, c = idx & 127;
+        if (m0 + r0 + r < D && n0 + c < D) {
+            const long o = (long)(m0 + r0 + r) * D + n0 + c;
+            const float v = tile[r * RED_LD + c];
+            as_global(cov)[o] = accumulate ? (as_global(cov)[o] + v) : v;
+        }
+    }
+    if (ti != tj) {                                             // mirror: element (r, c) of the tile lands at row n0+c, column m0+r
+        for (int idx = threadIdx.x; idx < rows * BN; idx += 256) {
+            const int c = idx / rows, r = idx - c * rows;       // r fastest: runs of `rows` consecutive floats
+            if (m0 + r0 + r < D && n0 + c < D) {
+                const long o = (long)(n0 + c) * D + m0 + r0 + r;
+                const float v = tile[r * RED_LD + c];
+                as_global(cov)[o] = accumulate ? (as_global(cov)[o] + v) : v;
+            }
+        }
     }
 }
 
@@ -184,18 +228,20 @@ __global__ __launch_bounds__(256) void nsgp_cov_linear_kernel(const float* __res
     }
 }
 
-// split factor along L: enough workgroups to fill 256 CUs x 2, each split >= 4 K-steps
-static void cov_split(int D, int L, int* S, int* l_chunk) {
+// stream-K launch shape: G = tiles x K-steps flattened units over P workgroups (all resident: 2 per CU)
+struct CovPlan {
+    int nk;
+    long tiles, G, P;
+};
+
+static CovPlan cov_plan(int D, int L) {
     const int nb = (D + BM - 1) / BM;
-    const int tiles = nb * (nb + 1) / 2;
-    int s = (512 + tiles - 1) / tiles;
-    const int max_s = std::max(1, L / (4 * BK));
-    s = std::max(1, std::min(s, max_s));
-    int chunk = (L + s - 1) / s;
-    chunk = ((chunk + BK - 1) / BK) * BK;
-    s = (L + chunk - 1) / chunk;
-    *S = s;
-    *l_chunk = chunk;
+    CovPlan p;
+    p.nk = (L + BK - 1) / BK;
+    p.tiles = (long)nb * (nb + 1) / 2;
+    p.G = p.tiles * p.nk;
+    p.P = std::max<long>(1, std::min<long>(512, p.G / 4));     // at least 4 K-steps per workgroup
+    return p;
 }
 
 static size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
@@ -210,9 +256,8 @@ extern "C" size_t nsgp_cov_workspace_bytes(int cin, int h, int w, int kh, int kw
     const int Ho = (Hp - kh) / sh + 1, Wo = (Wp - kw) / sw + 1;
     if (Ho <= 0 || Wo <= 0) return 0;
     const int D = cin * kh * kw;
-    int S, chunk;
-    cov_split(D, Ho * Wo, &S, &chunk);
-    return align256((size_t)cin * Hp * Wp * 4) + (size_t)S * D * D * 4;
+    const CovPlan p = cov_plan(D, Ho * Wo);
+    return align256((size_t)cin * Hp * Wp * 4) + (size_t)(p.tiles + p.P) * BM * BN * 4;
 }
 
 extern "C" int nsgp_cov_accumulate_conv2d(const float* x, int batch, int cin, int h, int w, int kh, int kw, int sh,
@@ -226,20 +271,20 @@ extern "C" int nsgp_cov_accumulate_conv2d(const float* x, int batch, int cin, in
     const int Hp = h + 2 * ph, Wp = w + 2 * pw;
     const int Ho = (Hp - kh) / sh + 1, Wo = (Wp - kw) / sw + 1;
     ConvGeom g{cin * kh * kw, Ho * Wo, Wo, kh, kw, sh, sw, Hp, Wp};
-    int S, chunk;
-    cov_split(g.D, g.L, &S, &chunk);
+    const CovPlan p = cov_plan(g.D, g.L);
     float* xm = static_cast<float*>(workspace);
-    float* partial = reinterpret_cast<float*>(static_cast<char*>(workspace) + align256((size_t)cin * Hp * Wp * 4));
+    float* slabs = reinterpret_cast<float*>(static_cast<char*>(workspace) + align256((size_t)cin * Hp * Wp * 4));
     const long n_img = (long)cin * Hp * Wp;
     hipLaunchKernelGGL(nsgp_batch_mean_pad_kernel, dim3((unsigned)std::min<long>(4096, (n_img + 255) / 256)), dim3(256), 0, stream,
                        x, batch, cin, h, w, ph, pw, xm);
     NSGP_LAUNCH_CHECK();
     NSGP_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(nsgp_cov_syrk_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, SMEM_BYTES));
-    const int nb = (g.D + BM - 1) / BM;
-    hipLaunchKernelGGL(nsgp_cov_syrk_kernel, dim3(nb * (nb + 1) / 2, S), dim3(THREADS), SMEM_BYTES, stream, xm, g, chunk, partial);
+    hipLaunchKernelGGL(nsgp_cov_syrk_kernel, dim3((unsigned)p.P), dim3(THREADS), SMEM_BYTES, stream, xm, g, p.nk, p.G, slabs);
     NSGP_LAUNCH_CHECK();
-    const long n = (long)g.D * g.D;
-    hipLaunchKernelGGL(nsgp_cov_reduce_kernel, dim3((unsigned)std::min<long>(4096, (n + 255) / 256)), dim3(256), 0, stream, partial, S, g.D, cov, accumulate);
+    int bands = 2;                                              // >= 256 reduce workgroups, bands of 64 .. 4 rows
+    while (bands < 32 && p.tiles * bands < 256) bands *= 2;
+    hipLaunchKernelGGL(nsgp_cov_reduce_kernel, dim3((unsigned)p.tiles, bands), dim3(256), 0, stream, slabs, g.D, p.nk, p.G, p.P,
+                       BM / bands, cov, accumulate);
     NSGP_LAUNCH_CHECK();
     return NSGP_OK;
 }
