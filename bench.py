@@ -194,7 +194,7 @@ def cpu_baseline(table, seconds_budget=15.0):
                        "included on the CPU side (that favours the CPU number)")
 
 
-def end_to_end_training(N, dev, world, local_rank, basis_cache, steps, warmup, amp, batch_size=1, channels_last=False):
+def end_to_end_training(N, dev, world, local_rank, basis_cache, steps, warmup, amp, batch_size=1, channels_last=False, graphs=False):
     """SURVEY 8(d) "end-to-end img/s": the whole task-2 training step of cl_faster_rcnn_nsgp_repre_15_5_2.py on synthetic
     800x1344 batches -- teacher predict + pseudo-label filter, student forward (RPN + RoI losses + replay loss on the
     K=150 bank), backward (DDP bucketed RCCL all-reduce overlapped with it when world > 1) and the projected SGDNSCL
@@ -225,13 +225,15 @@ def end_to_end_training(N, dev, world, local_rank, basis_cache, steps, warmup, a
     model.train()
     # channels_last: only the ACTIVATIONS (the input image decides the layout of every convolution's output);
     # parameters stay contiguous -- the optimizer's [Cout x D] view of a conv weight is the reference's layout
+    batches = [synthetic_batch(batch_size, (15, 20), dev, seed=100 * local_rank + i) for i in range(4)]
+    if channels_last:
+        batches = [(x.contiguous(memory_format=torch.channels_last), s) for x, s in batches]
+    if graphs:      # hipGraphs for the static-shape convolutional trunk (student fwd+bwd, teacher fwd); see detection/graphs.py
+        model.enable_graphs(batches[0][0], torch.bfloat16 if amp else None)
     net = model
     if world > 1:
         net = torch.nn.parallel.DistributedDataParallel(model, device_ids=[local_rank], broadcast_buffers=False,
                                                         gradient_as_bucket_view=True)
-    batches = [synthetic_batch(batch_size, (15, 20), dev, seed=100 * local_rank + i) for i in range(4)]
-    if channels_last:
-        batches = [(x.contiguous(memory_format=torch.channels_last), s) for x, s in batches]
     fwd_bwd, opt_ms = [], []
 
     def one_step(i):
@@ -275,7 +277,9 @@ def end_to_end_training(N, dev, world, local_rank, basis_cache, steps, warmup, a
         opt_ms.append(e1.elapsed_time(e2))
     finite = all(bool(torch.isfinite(v)) for v in losses.values())
     out = {"img_s": world * batch_size * steps / elapsed, "ms_per_step": elapsed / steps * 1e3, "steps": steps, "warmup": warmup,
-           "batch_per_gpu": batch_size, "memory_format": "channels_last" if channels_last else "contiguous (NCHW)", "image": "3x800x1344 (1333x800 padded to /32)", "n_gpus": world,
+           "batch_per_gpu": batch_size,
+           "hip_graphs": "backbone + FPN + RPN convolutions: student forward/backward and teacher forward replayed from captured graphs" if graphs else "off",
+           "memory_format": "channels_last" if channels_last else "contiguous (NCHW)", "image": "3x800x1344 (1333x800 padded to /32)", "n_gpus": world,
            "teacher_student_fwd_bwd_ms": sum(fwd_bwd) / len(fwd_bwd), "optimizer_step_ms": sum(opt_ms) / len(opt_ms),
            "nsgp_kernels_ms": update_ms + gemm_ms, "projected_layers": n_proj,
            "trainable_tensors": sum(len(g["params"]) for g in opt.param_groups),
@@ -298,6 +302,8 @@ def main():
     ap.add_argument("--no-end-to-end", action="store_true", help="skip the end-to-end training img/s section")
     ap.add_argument("--e2e-steps", type=int, default=20)
     ap.add_argument("--e2e-f32", action="store_true", help="run the detector of the end-to-end section in fp32 instead of bf16 autocast")
+    ap.add_argument("--e2e-graphs", action="store_true", help="end-to-end section with hipGraph capture of the convolutional trunk "
+                    "(measured SLOWER on this stack: 47.9 vs 44.9 ms per step, so off by default)")
     ap.add_argument("--amp", action="store_true", help="run the replay head's GEMMs under bf16 autocast (measured 7x SLOWER "
                     "than fp32 on this image's hipBLASLt for the M=150 shapes: 12.4 vs 1.66 ms per step, so off by default)")
     args = ap.parse_args()
@@ -407,7 +413,10 @@ def main():
         allreduce_ms = (time.perf_counter() - t_ar) / 10 * 1e3
     e2e = None
     if not args.no_end_to_end:      # every rank takes part (DDP); the hot-path numbers above are already in the bag
-        e2e = end_to_end_training(N, dev, world, local_rank, cache, args.e2e_steps, 3, not args.e2e_f32)
+        e2e = end_to_end_training(N, dev, world, local_rank, cache, args.e2e_steps, 3, not args.e2e_f32, graphs=args.e2e_graphs)
+        if not args.e2e_f32 and world == 1:    # the same step with an fp32 detector, for reference beside the bf16 number
+            f32 = end_to_end_training(N, dev, world, local_rank, cache, max(4, args.e2e_steps // 2), 3, False)
+            e2e["f32_detector"] = {k: f32[k] for k in ("img_s", "ms_per_step", "teacher_student_fwd_bwd_ms", "optimizer_step_ms", "losses_finite")}
     if rank == 0:
         flops, abytes, ntiles, nproj = opt.plan_stats()
         # dominant kernel = the grouped projection GEMM: HIP events recorded by the library around

@@ -90,6 +90,55 @@ def test_detector_modes(N, dev):
         model(x, samples, mode="bogus")
 
 
+def test_graphed_trunk_matches_eager(N, dev):
+    """hipGraph replay of backbone + FPN + RPN convolutions (student fwd/bwd, teacher fwd) gives the eager losses and
+    gradients; parameter names are untouched; eval-mode passes stay eager so covariance hooks still fire."""
+    from nsgp_repre_amd.detection import build_faster_rcnn
+    torch.manual_seed(0)
+    model = build_faster_rcnn(width=16, fc_out_channels=64, task_id=2).to(dev)
+    mix = N.runner.br_nullspace_runner.NullSpaceTaskMixin()
+    mix.task_id = 2
+    mix.attach_teacher(model)
+    model.train()
+    names = [n for n, _ in model.named_parameters()]
+    x, samples = _batches(dev, 1, (15, 20), 0)[0]
+
+    def run():
+        torch.manual_seed(11)                                  # the samplers draw from the default generator
+        model.zero_grad()
+        losses = model(x, copy.deepcopy(samples), mode="loss")
+        sum(v for k, v in losses.items() if "loss" in k).backward()
+        return ({k: v.detach().clone() for k, v in losses.items()},
+                {n: p.grad.detach().clone() for n, p in model.named_parameters() if p.grad is not None})
+
+    l0, g0 = run()
+    model.enable_graphs(x)
+    assert [n for n, _ in model.named_parameters()] == names
+    for _ in range(2):                                          # replay twice: static buffers are reused
+        l1, g1 = run()
+        for k in l0:
+            torch.testing.assert_close(l1[k], l0[k], rtol=1e-4, atol=1e-5)
+        assert set(g1) == set(g0)
+        for n in g0:
+            assert _rel(g1[n], g0[n]) <= 1e-3, n
+    # a different input shape falls back to the eager path
+    x2, s2 = _batches(dev, 1, (15, 20), 1, h=128, w=160)[0]
+    assert all(torch.isfinite(v) for v in model(x2, s2, mode="loss").values())
+    # eval mode: eager, forward hooks fire
+    fired = []
+    h = model.backbone.layer2[0].conv1.register_forward_hook(lambda m, i, o: fired.append(1))
+    model.eval()
+    with torch.no_grad():
+        model(x, copy.deepcopy(samples), mode="nullspace")
+    h.remove()
+    assert fired
+
+
+def _rel(a, b):
+    a, b = a.detach().double(), b.detach().double()
+    return ((a - b).abs().max() / b.abs().max().clamp_min(1e-30)).item()
+
+
 def test_two_task_cycle_on_the_detector(N, dev):
     """The reference's whole flow on a narrow R-50-FPN: task 1 on classes 0-14 (3 steps), end-of-task covariance
     pass under the hooks + RoI dump; task 2 on classes 15-19 with the teacher, the prototype bank from task 1's

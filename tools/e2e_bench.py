@@ -17,11 +17,12 @@ def main():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--batch", type=int, default=1)
     ap.add_argument("--channels-last", action="store_true")
+    ap.add_argument("--graphs", action="store_true")
     args = ap.parse_args()
     import nsgp_repre_amd as N
     torch.cuda.set_device(0)
     dev = torch.device("cuda", 0)
-    out = bench.end_to_end_training(N, dev, 1, 0, {}, args.steps, 3, not args.f32, args.batch, args.channels_last)
+    out = bench.end_to_end_training(N, dev, 1, 0, {}, args.steps, 3, not args.f32, args.batch, args.channels_last, args.graphs)
     print(json.dumps(out))
 
 
