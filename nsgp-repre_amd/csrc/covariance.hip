@@ -240,7 +240,7 @@ static CovPlan cov_plan(int D, int L) {
     p.nk = (L + BK - 1) / BK;
     p.tiles = (long)nb * (nb + 1) / 2;
     p.G = p.tiles * p.nk;
-    p.P = std::max<long>(1, std::min<long>(512, p.G / 4));     // at least 4 K-steps per workgroup
+    p.P = std::max<long>(1, std::min<long>(512, p.G / 16));    // at least 16 K-steps per workgroup (each segment costs a 64 KB slab)
     return p;
 }
 
@@ -275,7 +275,8 @@ extern "C" int nsgp_cov_accumulate_conv2d(const float* x, int batch, int cin, in
     float* xm = static_cast<float*>(workspace);
     float* slabs = reinterpret_cast<float*>(static_cast<char*>(workspace) + align256((size_t)cin * Hp * Wp * 4));
     const long n_img = (long)cin * Hp * Wp;
-    hipLaunchKernelGGL(nsgp_batch_mean_pad_kernel, dim3((unsigned)std::min<long>(4096, (n_img + 255) / 256)), dim3(256), 0, stream,
+    if (batch == 1 && ph == 0 && pw == 0) xm = const_cast<float*>(x);   // the image IS its own batch mean: no copy (all 1x1 convs at batch 1)
+    else hipLaunchKernelGGL(nsgp_batch_mean_pad_kernel, dim3((unsigned)std::min<long>(4096, (n_img + 255) / 256)), dim3(256), 0, stream,
                        x, batch, cin, h, w, ph, pw, xm);
     NSGP_LAUNCH_CHECK();
     NSGP_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(nsgp_cov_syrk_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, SMEM_BYTES));
