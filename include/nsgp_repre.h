@@ -32,7 +32,7 @@ extern "C" {
 #define NSGP_ERR_WORKSPACE (-3) /* workspace too small */
 #define NSGP_ERR_LIMIT (-4)     /* a fixed capacity was exceeded (e.g. > NSGP_MAX_HYPER combos) */
 
-#define NSGP_ABI_VERSION 2
+#define NSGP_ABI_VERSION 3
 #define NSGP_MAX_HYPER 32 /* distinct hyper-parameter sets per plan step */
 
 int nsgp_abi_version(void);
@@ -170,9 +170,13 @@ int nsgp_build_projector(const float* V, int D, int first_col, int normalise, fl
  *   feats: [N x D] fp32.  norm_scratch: [N] floats (||row||_2, written by the call).
  *   counts: [N] int64 (the reference's `.long().sum(-1)`).
  *   bitmask: [N x words] uint64, words = (N+63)/64; bit j of row i = (sim[i][j] >= thr).
+ *   workspace: >= repre_sim_workspace_bytes(n, d) (fp32 partial tiles of the stream-K split used for
+ *   classes with few rows; 0 -- and workspace may be NULL -- when N alone fills the chip).
  * ------------------------------------------------------------------------ */
+size_t repre_sim_workspace_bytes(int n, int d);
 int repre_sim_counts(const float* feats, int n, int d, float thr, float* norm_scratch,
-                     int64_t* counts, uint64_t* bitmask, void* stream);
+                     int64_t* counts, uint64_t* bitmask, void* workspace, size_t workspace_bytes,
+                     void* stream);
 /* out[d] = mean over rows i with bit i set in `rowmask` (words uint64); if rowmask==NULL all rows.
  * n_selected is the popcount (caller-computed).  standard_roi_replay_head.py:413,443.
  * workspace: >= repre_masked_mean_workspace_bytes(n, d) (per-row-segment partial sums). */

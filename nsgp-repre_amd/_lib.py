@@ -56,7 +56,9 @@ SIGNATURES = {
     "repre_nms": (C.c_int, [C.c_void_p, C.c_int, C.c_float, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
     "repre_replay_ce_forward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "repre_replay_ce_backward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
-    "repre_sim_counts": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "repre_sim_workspace_bytes": (C.c_size_t, [C.c_int, C.c_int]),
+    "repre_sim_counts": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t,
+                                   C.c_void_p]),
     "repre_masked_mean_workspace_bytes": (C.c_size_t, [C.c_int, C.c_int]),
     "repre_masked_mean": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
 }

@@ -10,6 +10,11 @@
 // computed, and the epilogue turns each 32x32 accumulator block into 32-bit mask words with
 // wave ballots -- stored once for (row, col-segment) and once, transposed, for (col, row-segment).
 // Every 32-bit word of the bit matrix is written by exactly one wave: no atomics, deterministic.
+// A class with few RoIs has few tiles (N=300: 6) and a long contraction (D=12544: 392 K-steps) -- six
+// workgroups on a 256-CU chip.  Below 256 tiles the flattened (tile, K-step) space is therefore cut
+// stream-K style into equal ranges over up to 512 resident workgroups (as in covariance.hip): segments
+// write fp32 partial tiles, a second launch sums each tile's segments in workgroup order, thresholds
+// and emits the same mask words.
 #include <algorithm>
 
 #include "common.hpp"
@@ -27,6 +32,14 @@ __global__ __launch_bounds__(256) void repre_row_norm_kernel(const float* __rest
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
     __syncthreads();
     if (threadIdx.x == 0) nrm[blockIdx.x] = sqrtf((red[0] + red[1]) + (red[2] + red[3]));
+}
+
+// FAST operand pointers with the row index clamped to N-1: tiles that hang over the last row re-read it
+// (in-bounds, unguarded float4 loads); whatever those rows produce is dropped by the `row < N` tests downstream.
+__device__ __forceinline__ void clamped_row_bases(const float* base, long ld, int row0, int n_rows, const float* (&ptr)[4]) {
+    const int t = threadIdx.x;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) ptr[j] = base + (long)min(row0 + (t >> 3) + 32 * j, n_rows - 1) * ld + (t & 7) * 4;
 }
 
 template <bool FAST>
@@ -50,11 +63,21 @@ __global__ __launch_bounds__(256, 2) void repre_sim_mask_kernel(const float* __r
         db[j] = rb_ < N ? nrm[rb_] : 1.0f;
     }
     float ra[2][4][4], rb[2][4][4];
+    const float *pa[4], *pb[4];
+    if (FAST) {
+        clamped_row_bases(F, D, m0, N, pa);
+        clamped_row_bases(F, D, n0, N, pb);
+    }
     mfma_pipeline<true>(
         (D + BK - 1) / BK, smem, acc,
         [&](int k, auto s) {
-            stage_rows<FAST>(F, D, N, D, m0, k * BK, ra[decltype(s)::value]);
-            stage_rows<FAST>(F, D, N, D, n0, k * BK, rb[decltype(s)::value]);
+            if (FAST) {
+                load4(pa, (long)k * BK, ra[decltype(s)::value]);
+                load4(pb, (long)k * BK, rb[decltype(s)::value]);
+            } else {
+                stage_rows<false>(F, D, N, D, m0, k * BK, ra[decltype(s)::value]);
+                stage_rows<false>(F, D, N, D, n0, k * BK, rb[decltype(s)::value]);
+            }
         },
         [&](float* img, int, auto s) { write_rows_div(img, ra[decltype(s)::value], da); },
         [&](float* img, int, auto s) { write_rows_div(img, rb[decltype(s)::value], db); });
@@ -87,6 +110,138 @@ __global__ __launch_bounds__(256, 2) void repre_sim_mask_kernel(const float* __r
                     mask32[(long)col * words32 + row_blk / 32] = colbits | other;
             }
         }
+}
+
+__host__ __device__ __forceinline__ long sim_sk_begin(long w, long G, long P) { return w * G / P; }
+__host__ __device__ __forceinline__ long sim_sk_owner(long gidx, long G, long P) { return ((gidx + 1) * P - 1) / G; }
+__device__ __forceinline__ void sim_tile_of(int t, int nb, int& ti, int& tj) {
+    ti = 0;
+    int rem = t;
+    while (rem >= nb - ti) { rem -= nb - ti; ++ti; }
+    tj = ti + rem;
+}
+
+// stream-K phase 1: workgroup w contracts its contiguous range of (tile, K-step) units; segment -> slab (tile + w)
+template <bool FAST>
+__global__ __launch_bounds__(256, 2) void repre_sim_partial_kernel(const float* __restrict__ F, int N, int D,
+                                                                   const float* __restrict__ nrm, int nk, long G,
+                                                                   float* __restrict__ slabs) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int nb = (N + BM - 1) / BM;
+    const long P = gridDim.x, w = blockIdx.x;
+    const int t = threadIdx.x;
+    long gi = sim_sk_begin(w, G, P);
+    const long g_end = sim_sk_begin(w + 1, G, P);
+    float ra[2][4][4], rb[2][4][4];
+    while (gi < g_end) {
+        const int tile = (int)(gi / nk);
+        const int ja = (int)(gi - (long)tile * nk);
+        const int jb = (int)min((long)nk, ja + (g_end - gi));
+        int ti, tj;
+        sim_tile_of(tile, nb, ti, tj);
+        const int m0 = ti * BM, n0 = tj * BN;
+        float da[4], db[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int ra_ = m0 + (t >> 3) + 32 * j, rb_ = n0 + (t >> 3) + 32 * j;
+            da[j] = ra_ < N ? nrm[ra_] : 1.0f;
+            db[j] = rb_ < N ? nrm[rb_] : 1.0f;
+        }
+        f32x16 acc[2][2];
+        zero_acc(acc);
+        const float *pa[4], *pb[4];
+        if (FAST) {
+            clamped_row_bases(F, D, m0, N, pa);
+            clamped_row_bases(F, D, n0, N, pb);
+        }
+        mfma_pipeline<true>(
+            jb - ja, smem, acc,
+            [&](int k, auto s) {
+                if (FAST) {
+                    load4(pa, (long)(ja + k) * BK, ra[decltype(s)::value]);
+                    load4(pb, (long)(ja + k) * BK, rb[decltype(s)::value]);
+                } else {
+                    stage_rows<false>(F, D, N, D, m0, (ja + k) * BK, ra[decltype(s)::value]);
+                    stage_rows<false>(F, D, N, D, n0, (ja + k) * BK, rb[decltype(s)::value]);
+                }
+            },
+            [&](float* img, int, auto s) { write_rows_div(img, ra[decltype(s)::value], da); },
+            [&](float* img, int, auto s) { write_rows_div(img, rb[decltype(s)::value], db); });
+        float* out = slabs + ((long)tile + w) * (BM * BN);
+        acc_to_lds(smem, acc);
+        for_each_row4(smem, [&](int r, int col, float4 v) {
+            f32x4 q;
+            q[0] = v.x; q[1] = v.y; q[2] = v.z; q[3] = v.w;
+            *(gf32x4*)(out + r * BN + col) = q;
+        });
+        __syncthreads();
+        gi += jb - ja;
+    }
+}
+
+constexpr int SIM_LD = BN + 1;
+
+// stream-K phase 2, one workgroup per tile: similarity = sum of the tile's segments (workgroup order), then the
+// mask words: (row, 32-column word) for the tile and, off the diagonal, (column, 32-row word) for its mirror.
+__global__ __launch_bounds__(256) void repre_sim_finish_kernel(const float* __restrict__ slabs, int N, int nk, long G, long P,
+                                                               float thr, uint32_t* __restrict__ mask32, int words32) {
+    extern __shared__ __attribute__((aligned(16))) float tile[];   // [BM][SIM_LD]
+    const int nb = (N + BM - 1) / BM;
+    const int t = blockIdx.x;
+    int ti, tj;
+    sim_tile_of(t, nb, ti, tj);
+    const int m0 = ti * BM, n0 = tj * BN;
+    const long w_first = sim_sk_owner((long)t * nk, G, P), w_last = sim_sk_owner((long)(t + 1) * nk - 1, G, P);
+    for (int idx = threadIdx.x; idx < BM * BN / 4; idx += 256) {
+        const int r = idx / (BN / 4), c4 = (idx - r * (BN / 4)) * 4;
+        f32x4 sum = *(const gf32x4*)(slabs + ((long)t + w_first) * (BM * BN) + r * BN + c4);
+        for (long w = w_first + 1; w <= w_last; ++w) {
+            const f32x4 v = *(const gf32x4*)(slabs + ((long)t + w) * (BM * BN) + r * BN + c4);
+            sum[0] += v[0]; sum[1] += v[1]; sum[2] += v[2]; sum[3] += v[3];
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) tile[r * SIM_LD + c4 + e] = sum[e];
+    }
+    __syncthreads();
+    for (int item = threadIdx.x; item < BM * 4; item += 256) {
+        const int r = item >> 2, wq = item & 3;
+        const int row = m0 + r, word = n0 / 32 + wq;
+        if (row < N && word < words32) {
+            uint32_t bits = 0;
+            for (int c = 0; c < 32; ++c)
+                if (n0 + wq * 32 + c < N && tile[r * SIM_LD + wq * 32 + c] >= thr) bits |= 1u << c;
+            mask32[(long)row * words32 + word] = bits;
+        }
+    }
+    if (ti != tj) {
+        for (int item = threadIdx.x; item < BN * 4; item += 256) {
+            const int c = item >> 2, wq = item & 3;
+            const int row = n0 + c, word = m0 / 32 + wq;
+            if (row < N && word < words32) {
+                uint32_t bits = 0;
+                for (int r = 0; r < 32; ++r)
+                    if (m0 + wq * 32 + r < N && tile[(wq * 32 + r) * SIM_LD + c] >= thr) bits |= 1u << r;
+                mask32[(long)row * words32 + word] = bits;
+            }
+        }
+    }
+}
+
+struct SimPlan {
+    int nk;
+    long tiles, G, P;
+    bool stream_k;
+};
+
+static SimPlan sim_plan(int n, int d) {
+    const int nb = (n + BM - 1) / BM;
+    SimPlan p;
+    p.nk = (d + BK - 1) / BK;
+    p.tiles = (long)nb * (nb + 1) / 2;
+    p.G = p.tiles * p.nk;
+    p.P = std::max<long>(1, std::min<long>(512, p.G / 16));
+    p.stream_k = p.tiles < 256 && p.P > p.tiles;     // enough tiles fill the chip by themselves
+    return p;
 }
 
 // counts[i] = popcount of row i (the reference's `.long().sum(-1)`, int64)
@@ -129,25 +284,45 @@ static int mean_segments(int n) { return std::max(1, std::min(64, (n + 127) / 12
 
 using namespace nsgp;
 
+extern "C" size_t repre_sim_workspace_bytes(int n, int d) {
+    if (n <= 0 || d <= 0) return 0;
+    const SimPlan p = sim_plan(n, d);
+    return p.stream_k ? (size_t)(p.tiles + p.P) * BM * BN * 4 : 0;
+}
+
 extern "C" int repre_sim_counts(const float* feats, int n, int d, float thr, float* norm_scratch, int64_t* counts,
-                                uint64_t* bitmask, void* stream_) {
+                                uint64_t* bitmask, void* workspace, size_t workspace_bytes, void* stream_) {
     if (!feats || !norm_scratch || !counts || !bitmask || n <= 0 || d <= 0) return fail(NSGP_ERR_INVALID, "repre_sim_counts: bad argument");
+    const SimPlan p = sim_plan(n, d);
+    if (p.stream_k && (!workspace || workspace_bytes < repre_sim_workspace_bytes(n, d)))
+        return fail(NSGP_ERR_WORKSPACE, "repre_sim_counts: workspace %zu < %zu", workspace_bytes, repre_sim_workspace_bytes(n, d));
     hipStream_t stream = static_cast<hipStream_t>(stream_);
     const int words32 = 2 * ((n + 63) / 64);
     hipLaunchKernelGGL(repre_row_norm_kernel, dim3(n), dim3(256), 0, stream, feats, n, d, norm_scratch);
     NSGP_LAUNCH_CHECK();
     // words past the last 128-column tile boundary are never touched by a tile: clear the matrix first
     NSGP_HIP(hipMemsetAsync(bitmask, 0, (size_t)n * words32 * 4, stream));
-    const int nb = (n + BM - 1) / BM;
-    const int tiles = nb * (nb + 1) / 2;
-    const bool fast = (d % BK == 0) && (d % 4 == 0) && aligned16(feats) && (n % BM == 0);
+    const bool fast = (d % BK == 0) && aligned16(feats);   // any N: rows past the end are clamped (clamped_row_bases)
     uint32_t* m32 = reinterpret_cast<uint32_t*>(bitmask);
-    if (fast) {
+    if (p.stream_k) {
+        float* slabs = static_cast<float*>(workspace);
+        if (fast) {
+            NSGP_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(repre_sim_partial_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, SMEM_BYTES));
+            hipLaunchKernelGGL(repre_sim_partial_kernel<true>, dim3((unsigned)p.P), dim3(THREADS), SMEM_BYTES, stream, feats, n, d, norm_scratch, p.nk, p.G, slabs);
+        } else {
+            NSGP_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(repre_sim_partial_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, SMEM_BYTES));
+            hipLaunchKernelGGL(repre_sim_partial_kernel<false>, dim3((unsigned)p.P), dim3(THREADS), SMEM_BYTES, stream, feats, n, d, norm_scratch, p.nk, p.G, slabs);
+        }
+        NSGP_LAUNCH_CHECK();
+        const size_t lds = (size_t)BM * SIM_LD * 4;
+        NSGP_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(repre_sim_finish_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(repre_sim_finish_kernel, dim3((unsigned)p.tiles), dim3(256), lds, stream, slabs, n, p.nk, p.G, p.P, thr, m32, words32);
+    } else if (fast) {
         NSGP_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(repre_sim_mask_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, SMEM_BYTES));
-        hipLaunchKernelGGL(repre_sim_mask_kernel<true>, dim3(tiles), dim3(THREADS), SMEM_BYTES, stream, feats, n, d, norm_scratch, thr, m32, words32);
+        hipLaunchKernelGGL(repre_sim_mask_kernel<true>, dim3((unsigned)p.tiles), dim3(THREADS), SMEM_BYTES, stream, feats, n, d, norm_scratch, thr, m32, words32);
     } else {
         NSGP_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(repre_sim_mask_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, SMEM_BYTES));
-        hipLaunchKernelGGL(repre_sim_mask_kernel<false>, dim3(tiles), dim3(THREADS), SMEM_BYTES, stream, feats, n, d, norm_scratch, thr, m32, words32);
+        hipLaunchKernelGGL(repre_sim_mask_kernel<false>, dim3((unsigned)p.tiles), dim3(THREADS), SMEM_BYTES, stream, feats, n, d, norm_scratch, thr, m32, words32);
     }
     NSGP_LAUNCH_CHECK();
     hipLaunchKernelGGL(repre_count_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, m32, n, words32, reinterpret_cast<long long*>(counts));

@@ -5,7 +5,7 @@
 // reproduced.  PyTorch runs softmax, log_softmax, nll_loss (+ their three backward kernels) on a
 // [K x C] matrix with K <= 400 rows and C <= 81 columns: pure launch overhead.  Here one wave64 owns
 // a row: two wave-wide max/sum reductions give q = softmax(s) and lse = logsumexp(q); the forward is a
-// single workgroup (ordered, deterministic mean), the backward one wave per row:
+// single 16-wave workgroup (ordered, deterministic mean), the backward one wave per row:
 //     dL/dq_j = (softmax(q)_j - [j == y]) / K,      ds_i = q_i * (dq_i - sum_j dq_j q_j).
 #include "common.hpp"
 
@@ -43,12 +43,15 @@ __device__ __forceinline__ float row_double_softmax(const float* __restrict__ ro
     return m2 + logf(s2);
 }
 
-__global__ __launch_bounds__(256) void repre_replay_ce_fwd_kernel(const float* __restrict__ scores, const long long* __restrict__ labels,
-                                                                  int K, int C, float* __restrict__ loss_out) {
-    __shared__ float part[4];
+constexpr int CE_FWD_WAVES = 16;   // one workgroup of 16 waves: K = 150 rows -> <= 10 dependent row passes per wave
+
+__global__ __launch_bounds__(64 * CE_FWD_WAVES) void repre_replay_ce_fwd_kernel(const float* __restrict__ scores,
+                                                                               const long long* __restrict__ labels, int K, int C,
+                                                                               float* __restrict__ loss_out) {
+    __shared__ float part[CE_FWD_WAVES];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     float acc = 0.0f;
-    for (int r = wave; r < K; r += 4) {
+    for (int r = wave; r < K; r += CE_FWD_WAVES) {
         float q[4];
         const float lse = row_double_softmax(scores + (long)r * C, C, lane, q);
         const int y = (int)labels[r];
@@ -60,7 +63,11 @@ __global__ __launch_bounds__(256) void repre_replay_ce_fwd_kernel(const float* _
     }
     if (lane == 0) part[wave] = acc;
     __syncthreads();
-    if (threadIdx.x == 0) *loss_out = ((part[0] + part[1]) + (part[2] + part[3])) / (float)K;
+    if (threadIdx.x == 0) {              // fixed order: deterministic
+        float t = 0.0f;
+        for (int w = 0; w < CE_FWD_WAVES; ++w) t += part[w];
+        *loss_out = t / (float)K;
+    }
 }
 
 __global__ __launch_bounds__(256) void repre_replay_ce_bwd_kernel(const float* __restrict__ scores, const long long* __restrict__ labels,
@@ -95,7 +102,7 @@ using namespace nsgp;
 extern "C" int repre_replay_ce_forward(const float* scores, const int64_t* labels, int n_rows, int n_cols, float* loss_out, void* stream_) {
     if (!scores || !labels || !loss_out || n_rows <= 0 || n_cols <= 0) return fail(NSGP_ERR_INVALID, "repre_replay_ce_forward: bad argument");
     if (n_cols > CE_MAX_COLS) return fail(NSGP_ERR_LIMIT, "repre_replay_ce_forward: %d columns > %d", n_cols, CE_MAX_COLS);
-    hipLaunchKernelGGL(repre_replay_ce_fwd_kernel, dim3(1), dim3(256), 0, static_cast<hipStream_t>(stream_), scores,
+    hipLaunchKernelGGL(repre_replay_ce_fwd_kernel, dim3(1), dim3(64 * CE_FWD_WAVES), 0, static_cast<hipStream_t>(stream_), scores,
                        reinterpret_cast<const long long*>(labels), n_rows, n_cols, loss_out);
     NSGP_LAUNCH_CHECK();
     return NSGP_OK;

@@ -117,9 +117,11 @@ def sim_counts(feats: torch.Tensor, thr: float = 0.6):
     norms = torch.empty(N, dtype=torch.float32, device=feats.device)
     counts = torch.empty(N, dtype=torch.int64, device=feats.device)
     bitmask = torch.empty(N, words, dtype=torch.int64, device=feats.device)
+    nbytes = lib.repre_sim_workspace_bytes(N, D)
+    ws = torch.empty(max(nbytes, 1), dtype=torch.uint8, device=feats.device)
     _lib.check(lib.repre_sim_counts(_dev(feats, "feats"), N, D, float(thr), _dev(norms, "norms"),
                                     _dev(counts, "counts", torch.int64), _dev(bitmask, "bitmask", torch.int64),
-                                    _stream()), "repre_sim_counts")
+                                    C.c_void_p(ws.data_ptr()), nbytes, _stream()), "repre_sim_counts")
     return counts, bitmask
 
 

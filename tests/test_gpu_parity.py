@@ -234,7 +234,10 @@ def test_sim_counts_vs_oracle_ragged(N, dev):
     """Counts and the bit matrix are integer results: bit-exact vs the oracle wherever no
     similarity sits within 1e-5 of the threshold (checked in fp64)."""
     from nsgp_repre_amd import ops
-    for n, d, seed in ((1, 64, 1), (5, 100, 2), (64, 256, 3), (129, 224, 4), (300, 512, 5)):
+    # the last four reach the stream-K split (few tiles, long D; fast and guarded loads) and the direct kernel with
+    # clamped fast loads on a ragged N
+    for n, d, seed in ((1, 64, 1), (5, 100, 2), (64, 256, 3), (129, 224, 4), (300, 512, 5), (300, 4096, 6), (700, 1000, 7),
+                       (1, 12544, 8), (3000, 64, 9)):
         Fc = torch.from_numpy(I.class_rois(n, d, seed, n_clusters=3))
         nrm = Fc / Fc.norm(dim=-1, keepdim=True)
         sim = nrm @ nrm.t()

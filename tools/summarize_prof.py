@@ -12,7 +12,7 @@ from collections import defaultdict
 
 src, dst = sys.argv[1], sys.argv[2]
 os.makedirs(dst, exist_ok=True)
-OURS = ("nsgp_", "repre_")
+OURS = ("nsgp_", "repre_", "nsgp::")
 
 
 def short(name):
