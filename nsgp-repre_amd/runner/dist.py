@@ -7,6 +7,10 @@ C2  ``all_gather_different_shape``  -- nsrunner_roi_replay.py:73-105.  The refer
      gather with 2*W zero-padded all-reduces per tensor (O(W*N) traffic per rank pair).  Here: one tiny
      all-gather of the row counts + ONE all-gather of the padded payload; same returned list.
 C3  the DDP gradient all-reduce stays PyTorch's (RCCL) and is not re-implemented.
+C4  ``sharded_eigens``              -- not in the reference, which repeats every layer's decomposition on every
+     rank (runner:655-657 under DDP): the layers are independent units, so each rank decomposes
+     the covariances `shard_by_cost` gives it (cost D^3) and broadcasts sigma [D] + V [D x D] to the others;
+     all ranks then hold bit-identical spectra and build identical projectors.
 Without an initialised process group (single GPU) every function is the identity.
 """
 from typing import Dict, List
@@ -77,4 +81,26 @@ def shard_by_cost(costs: List[float], world: int) -> List[int]:
         r = min(range(world), key=lambda x: load[x])
         owner[i] = r
         load[r] += costs[i]
+    return owner
+
+
+def sharded_eigens(optimizer, fea_in: Dict[str, torch.Tensor]) -> List[int]:
+    """``optimizer.get_eigens(fea_in)`` with the decompositions spread over the ranks; afterwards
+    ``optimizer.eigens[name]`` is complete and identical on every rank.  Returns the owner rank of each
+    decomposed layer (in the optimizer's own parameter order).  Single process: plain ``get_eigens``."""
+    names = [n for _, n, _p in optimizer._svd_named() if n in fea_in]
+    if not _active():
+        optimizer.get_eigens(fea_in)
+        return [0] * len(names)
+    world, rank = dist.get_world_size(), dist.get_rank()
+    owner = shard_by_cost([float(fea_in[n].shape[0]) ** 3 for n in names], world)
+    optimizer.get_eigens({n: fea_in[n] for n, o in zip(names, owner) if o == rank})
+    for n, o in zip(names, owner):
+        d, dev = fea_in[n].shape[0], fea_in[n].device
+        e = optimizer.eigens[n]
+        if o != rank:
+            e["eigen_value"] = torch.empty(d, dtype=torch.float32, device=dev)
+            e["eigen_vector"] = torch.empty(d, d, dtype=torch.float32, device=dev)
+        dist.broadcast(e["eigen_value"], src=o)
+        dist.broadcast(e["eigen_vector"], src=o)
     return owner

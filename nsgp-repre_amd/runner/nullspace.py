@@ -156,7 +156,7 @@ def update_optim_transforms(optimizer, covariance, ignore_keys: Sequence[str], o
         covariance = torch.load(covariance, map_location=device, weights_only=True)
     fea_in = {k: (v.to(device) if device is not None else v) for k, v in covariance.items()
               if not should_ignore(k, ignore_keys)}
-    optimizer.get_eigens(fea_in)
+    D.sharded_eigens(optimizer, fea_in)          # = get_eigens on one GPU; layers spread over the ranks under DDP (C4)
     optimizer.get_transforms(offset=offset)
     return fea_in
 

@@ -185,8 +185,23 @@ def _dist_worker(rank, world, port, q):
     t = torch.arange((rank + 2) * 3, dtype=torch.float32).reshape(rank + 2, 3) + 100 * rank
     parts = D.all_gather_different_shape(t)                   # C2, ragged first dim
     empty = D.all_gather_different_shape(torch.zeros(0, 5) if rank == 0 else torch.ones(2, 5))
+    # C4: every rank ends with every layer's spectrum, bit-identical to a single-process decomposition
+    shapes = {"backbone.l1.weight": 24, "backbone.l2.weight": 40, "neck.l3.weight": 16, "neck.l4.weight": 40, "neck.l5.weight": 8}
+    params = [torch.nn.Parameter(torch.zeros(4, d)) for d in shapes.values()]
+    fea = {}
+    for i, (n, d) in enumerate(shapes.items()):
+        x = torch.randn(3 * d, d, generator=torch.Generator().manual_seed(7 + i))
+        fea[n] = x.t() @ x
+    opt = N.SGDNSCL(params, lr=0.1, svd=True)
+    opt.param_groups[0]["names"] = list(shapes)
+    owner = D.sharded_eigens(opt, fea)
+    solo = N.SGDNSCL(params, lr=0.1, svd=True)
+    solo.param_groups[0]["names"] = list(shapes)
+    solo.get_eigens(fea)
+    same = all(torch.equal(opt.eigens[n]["eigen_value"], solo.eigens[n]["eigen_value"])
+               and torch.equal(opt.eigens[n]["eigen_vector"], solo.eigens[n]["eigen_vector"]) for n in shapes)
     q.put((rank, {k: v.numpy() for k, v in local.items()}, {k: v.numpy() for k, v in mine.items()},
-           [p.numpy() for p in parts], [e.shape for e in empty]))
+           [p.numpy() for p in parts], [e.shape for e in empty], owner, same))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -205,7 +220,8 @@ def test_exchange_steps_gloo_world2(N):
         assert p.exitcode == 0
     locals_ = [{k: torch.from_numpy(v) for k, v in g[1].items()} for g in got]
     ref = O.all_reduce_dict_sum(locals_)
-    for rank, _, reduced, parts, eshapes in got:
+    for rank, _, reduced, parts, eshapes, owner, same in got:
+        assert same and sorted(set(owner)) == [0, 1] and owner == got[0][5]     # both ranks work, and agree on who owns what
         for k in ref:
             np.testing.assert_allclose(reduced[k], ref[k].numpy(), rtol=1e-6)
         exp = O.all_gather_different_shape([torch.arange((r + 2) * 3, dtype=torch.float32).reshape(r + 2, 3) + 100 * r for r in range(2)])
