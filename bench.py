@@ -413,10 +413,15 @@ def main():
         allreduce_ms = (time.perf_counter() - t_ar) / 10 * 1e3
     e2e = None
     if not args.no_end_to_end:      # every rank takes part (DDP); the hot-path numbers above are already in the bag
-        e2e = end_to_end_training(N, dev, world, local_rank, cache, args.e2e_steps, 3, not args.e2e_f32, graphs=args.e2e_graphs)
-        if not args.e2e_f32 and world == 1:    # the same step with an fp32 detector, for reference beside the bf16 number
-            f32 = end_to_end_training(N, dev, world, local_rank, cache, max(4, args.e2e_steps // 2), 3, False)
-            e2e["f32_detector"] = {k: f32[k] for k in ("img_s", "ms_per_step", "teacher_student_fwd_bwd_ms", "optimizer_step_ms", "losses_finite")}
+        try:    # the hot-path measurement above must reach the JSON line whatever happens in this wider section
+            e2e = end_to_end_training(N, dev, world, local_rank, cache, args.e2e_steps, 3, not args.e2e_f32, graphs=args.e2e_graphs)
+            if not args.e2e_f32 and world == 1:    # the same step with an fp32 detector, for reference beside the bf16 number
+                f32 = end_to_end_training(N, dev, world, local_rank, cache, max(4, args.e2e_steps // 2), 3, False)
+                e2e["f32_detector"] = {k: f32[k] for k in ("img_s", "ms_per_step", "teacher_student_fwd_bwd_ms", "optimizer_step_ms", "losses_finite")}
+        except Exception as exc:    # reported, never hidden
+            import traceback
+            traceback.print_exc()
+            e2e = {"error": f"{type(exc).__name__}: {exc}"}
     if rank == 0:
         flops, abytes, ntiles, nproj = opt.plan_stats()
         # dominant kernel = the grouped projection GEMM: HIP events recorded by the library around
