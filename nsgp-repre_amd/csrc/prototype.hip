@@ -180,49 +180,50 @@ __global__ __launch_bounds__(256, 2) void repre_sim_partial_kernel(const float* 
 }
 
 constexpr int SIM_LD = BN + 1;
+constexpr int SIM_BAND = 32;     // rows per finishing workgroup = one 32-bit word of the mirrored mask
 
-// stream-K phase 2, one workgroup per tile: similarity = sum of the tile's segments (workgroup order), then the
-// mask words: (row, 32-column word) for the tile and, off the diagonal, (column, 32-row word) for its mirror.
+// stream-K phase 2, grid (tiles, 4): workgroup (t, b) owns the 32-row band b of tile t: similarity = sum of the
+// tile's segments (workgroup order) for those rows, then the mask words: (row, 32-column word) x 4 for each of
+// its rows and, off the diagonal, the one (column, 32-row word) its band contributes to each mirrored row.
 __global__ __launch_bounds__(256) void repre_sim_finish_kernel(const float* __restrict__ slabs, int N, int nk, long G, long P,
                                                                float thr, uint32_t* __restrict__ mask32, int words32) {
-    extern __shared__ __attribute__((aligned(16))) float tile[];   // [BM][SIM_LD]
+    __shared__ float tile[SIM_BAND * SIM_LD];
     const int nb = (N + BM - 1) / BM;
-    const int t = blockIdx.x;
+    const int t = blockIdx.x, band = blockIdx.y, r0 = band * SIM_BAND;
     int ti, tj;
     sim_tile_of(t, nb, ti, tj);
     const int m0 = ti * BM, n0 = tj * BN;
+    if (m0 + r0 >= N) return;
     const long w_first = sim_sk_owner((long)t * nk, G, P), w_last = sim_sk_owner((long)(t + 1) * nk - 1, G, P);
-    for (int idx = threadIdx.x; idx < BM * BN / 4; idx += 256) {
+    for (int idx = threadIdx.x; idx < SIM_BAND * BN / 4; idx += 256) {
         const int r = idx / (BN / 4), c4 = (idx - r * (BN / 4)) * 4;
-        f32x4 sum = *(const gf32x4*)(slabs + ((long)t + w_first) * (BM * BN) + r * BN + c4);
+        const long off = (long)(r0 + r) * BN + c4;
+        f32x4 sum = *(const gf32x4*)(slabs + ((long)t + w_first) * (BM * BN) + off);
         for (long w = w_first + 1; w <= w_last; ++w) {
-            const f32x4 v = *(const gf32x4*)(slabs + ((long)t + w) * (BM * BN) + r * BN + c4);
+            const f32x4 v = *(const gf32x4*)(slabs + ((long)t + w) * (BM * BN) + off);
             sum[0] += v[0]; sum[1] += v[1]; sum[2] += v[2]; sum[3] += v[3];
         }
 #pragma unroll
         for (int e = 0; e < 4; ++e) tile[r * SIM_LD + c4 + e] = sum[e];
     }
     __syncthreads();
-    for (int item = threadIdx.x; item < BM * 4; item += 256) {
-        const int r = item >> 2, wq = item & 3;
-        const int row = m0 + r, word = n0 / 32 + wq;
+    if (threadIdx.x < SIM_BAND * 4) {
+        const int r = threadIdx.x >> 2, wq = threadIdx.x & 3;
+        const int row = m0 + r0 + r, word = n0 / 32 + wq;
         if (row < N && word < words32) {
             uint32_t bits = 0;
             for (int c = 0; c < 32; ++c)
                 if (n0 + wq * 32 + c < N && tile[r * SIM_LD + wq * 32 + c] >= thr) bits |= 1u << c;
             mask32[(long)row * words32 + word] = bits;
         }
-    }
-    if (ti != tj) {
-        for (int item = threadIdx.x; item < BN * 4; item += 256) {
-            const int c = item >> 2, wq = item & 3;
-            const int row = n0 + c, word = m0 / 32 + wq;
-            if (row < N && word < words32) {
-                uint32_t bits = 0;
-                for (int r = 0; r < 32; ++r)
-                    if (m0 + wq * 32 + r < N && tile[(wq * 32 + r) * SIM_LD + c] >= thr) bits |= 1u << r;
-                mask32[(long)row * words32 + word] = bits;
-            }
+    } else if (ti != tj) {                                      // threads 128..255: one mirrored word per tile column
+        const int c = threadIdx.x - SIM_BAND * 4;
+        const int row = n0 + c, word = (m0 + r0) / 32;
+        if (row < N && word < words32) {
+            uint32_t bits = 0;
+            for (int r = 0; r < SIM_BAND; ++r)
+                if (m0 + r0 + r < N && tile[r * SIM_LD + c] >= thr) bits |= 1u << r;
+            mask32[(long)row * words32 + word] = bits;
         }
     }
 }
@@ -314,9 +315,7 @@ extern "C" int repre_sim_counts(const float* feats, int n, int d, float thr, flo
             hipLaunchKernelGGL(repre_sim_partial_kernel<false>, dim3((unsigned)p.P), dim3(THREADS), SMEM_BYTES, stream, feats, n, d, norm_scratch, p.nk, p.G, slabs);
         }
         NSGP_LAUNCH_CHECK();
-        const size_t lds = (size_t)BM * SIM_LD * 4;
-        NSGP_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(repre_sim_finish_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        hipLaunchKernelGGL(repre_sim_finish_kernel, dim3((unsigned)p.tiles), dim3(256), lds, stream, slabs, n, p.nk, p.G, p.P, thr, m32, words32);
+        hipLaunchKernelGGL(repre_sim_finish_kernel, dim3((unsigned)p.tiles, BM / SIM_BAND), dim3(256), 0, stream, slabs, n, p.nk, p.G, p.P, thr, m32, words32);
     } else if (fast) {
         NSGP_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(repre_sim_mask_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, SMEM_BYTES));
         hipLaunchKernelGGL(repre_sim_mask_kernel<true>, dim3((unsigned)p.tiles), dim3(THREADS), SMEM_BYTES, stream, feats, n, d, norm_scratch, thr, m32, words32);
