@@ -82,10 +82,7 @@ class PrototypeReplay:
         pre_idx = self.task_split[self.task_id]
         kept = torch.cat([cls_score[:, :pre_idx], cls_score[:, -1:]], dim=-1)
         labels = self.tmp_label.to(kept.device)
-        if kept.is_cuda and kept.dtype == torch.float32 and kept.shape[1] <= 256:
-            loss = ops.double_softmax_cross_entropy(kept, labels)        # fused wave-reduction kernels
-        else:   # CPU tensors (tests of the host logic) / autocast dtypes: the same formula through torch
-            loss = F.cross_entropy(kept.softmax(dim=-1), labels)
+        loss = ops.double_softmax_cross_entropy(kept, labels)   # fused wave-reduction kernels (fp32; GPU only, no torch fallback)
         results.update(replay_loss=dict(replay_loss_cls=loss))
         return results
 

@@ -244,6 +244,33 @@ def test_pseudo_label_filter_vs_oracle(N, dev):
             assert bool((ref_roi <= ref_rpn).all())          # roi_thresh >= rpn_thresh
 
 
+def test_replay_loss_through_the_head_vs_reference_golden(N, dev, golden_dir):
+    """G5 end to end on the GPU: bank -> Shared2FCBBoxHeadTask -> kept columns -> fused CE(softmax(.)) -> backward into
+    the shared FCs, against the reference's own loss and weight gradients."""
+    from test_runner_host import _g5_head
+    g = np.load(os.path.join(golden_dir, "g5_replay_loss.npz"))
+    head = _g5_head(N, dev)
+    bank, labels = I.g5_bank()
+
+    class Holder(N.roi_heads.PrototypeReplay):
+        pass
+    h = Holder()
+    h.bbox_head, h.task_split, h.task_id = head, I.G5_TASK_SPLIT, I.G5_TASK_ID
+    h.tmp_label, h.replay = torch.from_numpy(labels).to(dev), True
+    h.bbox_featss = torch.from_numpy(bank).reshape(-1, 4, 7, 7).to(dev)
+    res = h.replay_loss(h.bbox_featss)
+    loss = res["replay_loss"]["replay_loss_cls"]
+    np.testing.assert_allclose(loss.item(), g["loss"], rtol=2e-6)
+    loss.backward()
+    for i, m in enumerate(head.shared_fcs):
+        np.testing.assert_allclose(m.weight.grad.cpu().numpy(), g[f"gW_shared{i}"], rtol=1e-4, atol=1e-7)
+    losses = h.add_replay_loss(dict(loss_cls=torch.tensor(1.0, device=dev)))
+    assert set(losses) == {"loss_cls", "replay_loss_cls"}
+    with torch.autocast("cuda", dtype=torch.bfloat16):          # the bank pass stays fp32 inside an autocast step
+        inside = h.add_replay_loss({})["replay_loss_cls"]
+    assert inside.dtype == torch.float32 and abs(inside.item() - g["loss"]) <= 2e-6 * abs(float(g["loss"]))
+
+
 def test_fused_double_softmax_ce_vs_torch_and_golden(N, dev, golden_dir):
     """head:499 ``F.cross_entropy(cls_score.softmax(-1), labels)``: fused kernels vs torch's own ops
     (fp64 reference) on ragged sizes, and vs the reference's loss value of G5."""
