@@ -472,6 +472,27 @@ def main():
                                    "achieved_tflops": lr_flops / (lr_gemm_ms * 1e-3) / 1e12, "tiles_phase1": lt1, "tiles_phase2": lt2,
                                    "synthetic_rank": "r = D/16", "note": "opt-in (optimizer.low_rank=True); parity vs the dense form: tests/test_gpu_parity.py::test_low_rank_form_matches_dense_form"}
             opt.low_rank = False
+            # the AdamW flavour of the same step (schedule_1x_adamwnscl.py:21: lr 1e-4, weight_decay 0.1) over the same
+            # tensors, projectors and synthetic gradients -- row a3 of SURVEY 8; parity: the G1 adamw goldens
+            adamw = N.AdamWNSCL(params, lr=1e-4, weight_decay=0.1, svd=True)
+            adamw.param_groups[0]["names"] = names
+            for n, shape, proj in table:
+                if proj:
+                    adamw.transforms[n] = opt.transforms[n]
+            flat_grads.copy_(synth_flat)
+            for _ in range(3):
+                adamw.step()
+            torch.cuda.synchronize()
+            adamw.profile_begin(args.steps)
+            for _ in range(args.steps):
+                adamw.step()
+            torch.cuda.synchronize()
+            _, aw_update_ms, aw_gemm_ms = adamw.profile_end()
+            out["adamw_nscl"] = {"nsgp_step_ms": aw_update_ms + aw_gemm_ms, "elementwise_kernel_ms": aw_update_ms,
+                                 "projection_kernel_ms": aw_gemm_ms, "achieved_tflops": flops / (aw_gemm_ms * 1e-3) / 1e12,
+                                 "elementwise_hbm_gbs": 7 * 4 * flat_numel_real / (aw_update_ms * 1e-3) / 1e9,
+                                 "note": "AdamWNSCL.step, same table; elementwise bytes: g r, m r+w, v r+w, p r+w"}
+            del adamw
         if e2e is not None:
             out["end_to_end"] = e2e
         if world == 1:
