@@ -32,7 +32,7 @@ extern "C" {
 #define NSGP_ERR_WORKSPACE (-3) /* workspace too small */
 #define NSGP_ERR_LIMIT (-4)     /* a fixed capacity was exceeded (e.g. > NSGP_MAX_HYPER combos) */
 
-#define NSGP_ABI_VERSION 3
+#define NSGP_ABI_VERSION 4
 #define NSGP_MAX_HYPER 32 /* distinct hyper-parameter sets per plan step */
 
 int nsgp_abi_version(void);
@@ -79,6 +79,10 @@ typedef struct {
                            in 4*Cout*D*r FLOP instead of 2*Cout*D^2; otherwise the dense `proj` is used */
     float basis_scale;  /* 1/||P||_F for Frobenius-normalised projectors (SGD_NSCL.py:282-283), else 1 */
     int32_t reserved;
+    const void* proj_split; /* optional: the three-term bf16 split of proj^T written by nsgp_split_projector.  When every
+                           128-aligned projected tensor of a plan carries one, the dense projection runs on the bf16 matrix
+                           cores as six MFMAs per fp32-equivalent product (a0b0+a0b1+a1b0+a0b2+a1b1+a2b0, fp32
+                           accumulation; error vs fp64 equal to the fp32-MFMA path's).  NULL = fp32 MFMA */
 } nsgp_tensor_t;
 
 /* Per-step hyper-parameters of one param group (host values, fp64->fp32 as torch does). */
@@ -122,12 +126,20 @@ int nsgp_plan_stats(const nsgp_plan_t* plan, double* gemm_flops, double* algorit
 /* Layers that take the low-rank form and their FLOPs (sum 4*Cout*D*r), tile counts of its two phases. */
 int nsgp_plan_lowrank_stats(const nsgp_plan_t* plan, int* n_lowrank, double* lowrank_flops,
                             int* n_tiles_p1, int* n_tiles_p2);
+/* 1 if the plan's dense projection launch uses the three-term bf16 split (every fast tensor carried proj_split). */
+int nsgp_plan_uses_split_mfma(const nsgp_plan_t* plan);
 
 /* Per-launch timing with HIP events recorded on the launch stream (measurement only): between
  * _begin and _end each nsgp_plan_step records 3 events; _end synchronises on them and returns
  * the average duration of the elementwise launch and of the projection-GEMM launch(es). */
 int nsgp_plan_profile_begin(nsgp_plan_t* plan, int max_steps);
 int nsgp_plan_profile_end(nsgp_plan_t* plan, int* n_steps, float* update_ms_avg, float* gemm_ms_avg);
+
+/* Three-term bf16 split of the TRANSPOSE of a projector (proj = sum of the three terms to 24 mantissa bits), in the layout
+ * the split-MFMA projection kernel streams: [n][k/8][term][8] bf16, 6 bytes per element.  Once per projector per task.
+ * proj: [D x D] fp32 row-major; out: >= nsgp_split_projector_bytes(D) bytes, 16-byte aligned; D % 8 == 0. */
+size_t nsgp_split_projector_bytes(int D);
+int nsgp_split_projector(const float* proj, int D, void* out, void* stream);
 
 /* Stand-alone projection `out[rows x cols] (+)= scale * (a[rows x cols] @ proj[cols x cols])`
  * (SGD_NSCL.py:85-90 in isolation; accumulate=0 overwrites `out`).  Used by tests to check

@@ -20,6 +20,7 @@
 
 #include "common.hpp"
 #include "gemm_core.hpp"
+#include "gemm_bf16x3.hpp"
 
 namespace nsgp {
 
@@ -49,6 +50,7 @@ struct LayerDev {
     float* slabs;
     int rank, rpad, nsplit, kchunk;
     float basis_scale;
+    const __bf16* proj3;   // three-term bf16 split of proj^T (gemm_bf16x3.hpp), or null
 };
 
 struct TileDev {
@@ -203,7 +205,7 @@ __device__ __forceinline__ void store_tile(float* __restrict__ C, long ldc, int 
         }
 }
 
-template <int OPT, bool FAST>
+template <int OPT, bool FAST, bool X3 = false>
 __global__ __launch_bounds__(256, 2) void nsgp_project_kernel(const TileDev* __restrict__ tiles,
                                                               const LayerDev* __restrict__ layers,
                                                               const DynBlock* __restrict__ dyn) {
@@ -226,7 +228,9 @@ __global__ __launch_bounds__(256, 2) void nsgp_project_kernel(const TileDev* __r
     zero_acc(acc);
     // the grad pointer is only known at step time: a misaligned one (e.g. a view into a flat
     // bucket) takes the guarded scalar loader for the A operand only
-    if (!FAST || ((uintptr_t)A & 15u) == 0)
+    if (X3 && ((uintptr_t)A & 15u) == 0)          // six bf16 MFMAs per fp32-equivalent product (gemm_bf16x3.hpp)
+        gemm_tile_bf16x3(A, L.cols, L.proj3, L.cols, t.m0, t.n0, smem, acc);
+    else if (!FAST || ((uintptr_t)A & 15u) == 0)
         gemm_tile<FAST, FAST, false>(A, L.cols, L.proj, L.cols, L.rows, L.cols, L.cols, t.m0, t.n0, smem, acc);
     else
         gemm_tile<false, true, false>(A, L.cols, L.proj, L.cols, L.rows, L.cols, L.cols, t.m0, t.n0, smem, acc);
@@ -372,7 +376,7 @@ __global__ __launch_bounds__(256, 2) void nsgp_lowrank_p2_kernel(const TileDev* 
 template <typename K>
 static int enable_big_lds(K kernel) {
     NSGP_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel),
-                                 hipFuncAttributeMaxDynamicSharedMemorySize, SMEM_BYTES));
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, X3_SMEM_BYTES > SMEM_BYTES ? X3_SMEM_BYTES : SMEM_BYTES));
     return NSGP_OK;
 }
 
@@ -386,6 +390,7 @@ struct nsgp_plan {
     int n_layers = 0;
     int n_chunks = 0;
     int n_tiles_fast = 0, n_tiles_generic = 0;
+    bool use_x3 = false;        // dense fast tiles run the three-term bf16 split kernel
     double gemm_flops = 0, bytes = 0;
     TensorDev* d_tensors = nullptr;
     LayerDev* d_layers = nullptr;
@@ -466,6 +471,7 @@ extern "C" int nsgp_plan_create(nsgp_plan_t** out, const nsgp_tensor_t* tensors,
     std::vector<LayerDev> ld;
     std::vector<ChunkDev> cd;
     std::vector<char> layer_fast;
+    bool all_split = true;     // every fast dense layer carries the bf16 split of its projector
     double flops = 0, bytes = 0, lr_flops = 0;
     int n_lowrank = 0;
     const int lr_kchunk = lr_pick_kchunk(tensors, n);
@@ -485,7 +491,8 @@ extern "C" int nsgp_plan_create(nsgp_plan_t** out, const nsgp_tensor_t* tensors,
                 d.u = reinterpret_cast<float*>(static_cast<char*>(workspace) + ws_off);
                 ws_off += ((size_t)t.numel * 4 + 255) & ~(size_t)255;
             }
-            LayerDev L{t.param, t.state0, d.u, t.proj, i, t.rows, t.cols, t.hyper, nullptr, nullptr, nullptr, 0, 0, 0, 0, 1.0f};
+            LayerDev L{t.param, t.state0, d.u, t.proj, i, t.rows, t.cols, t.hyper, nullptr, nullptr, nullptr, 0, 0, 0, 0, 1.0f,
+                       static_cast<const __bf16*>(t.proj_split)};
             if (tensor_lowrank(t)) {
                 L.basis = t.basis;
                 L.rank = t.rank;
@@ -502,6 +509,7 @@ extern "C" int nsgp_plan_create(nsgp_plan_t** out, const nsgp_tensor_t* tensors,
             }
             ld.push_back(L);
             layer_fast.push_back(tensor_fast(t) && aligned16(t.param) && aligned16(t.state0) ? 1 : 0);
+            if (layer_fast.back() && !tensor_lowrank(t) && !(t.proj_split && aligned16(t.proj_split))) all_split = false;
             flops += 2.0 * t.rows * (double)t.cols * t.cols;
             bytes += 4.0 * (double)t.cols * t.cols;
         }
@@ -564,6 +572,7 @@ extern "C" int nsgp_plan_create(nsgp_plan_t** out, const nsgp_tensor_t* tensors,
     P->n_layers = (int)ld.size();
     P->n_chunks = (int)cd.size();
     P->n_tiles_fast = (int)fast_tiles.size();
+    P->use_x3 = all_split && !fast_tiles.empty();
     P->n_tiles_generic = (int)gen_tiles.size();
     P->gemm_flops = flops;
     P->bytes = bytes;
@@ -629,7 +638,8 @@ extern "C" int nsgp_plan_create(nsgp_plan_t** out, const nsgp_tensor_t* tensors,
     if ((rc = enable_big_lds(nsgp_lowrank_p1_kernel<NSGP_OPT_SGD>)) || (rc = enable_big_lds(nsgp_lowrank_p1_kernel<NSGP_OPT_ADAM>)) ||
         (rc = enable_big_lds(nsgp_lowrank_p2_kernel<NSGP_OPT_SGD>)) || (rc = enable_big_lds(nsgp_lowrank_p2_kernel<NSGP_OPT_ADAM>)) ||
         (rc = enable_big_lds(nsgp_project_kernel<NSGP_OPT_SGD, true>)) || (rc = enable_big_lds(nsgp_project_kernel<NSGP_OPT_SGD, false>)) ||
-        (rc = enable_big_lds(nsgp_project_kernel<NSGP_OPT_ADAM, true>)) || (rc = enable_big_lds(nsgp_project_kernel<NSGP_OPT_ADAM, false>))) {
+        (rc = enable_big_lds(nsgp_project_kernel<NSGP_OPT_ADAM, true>)) || (rc = enable_big_lds(nsgp_project_kernel<NSGP_OPT_ADAM, false>)) ||
+        (rc = enable_big_lds(nsgp_project_kernel<NSGP_OPT_SGD, true, true>)) || (rc = enable_big_lds(nsgp_project_kernel<NSGP_OPT_ADAM, true, true>))) {
         nsgp_plan_destroy(P);
         return rc;
     }
@@ -672,6 +682,19 @@ extern "C" int nsgp_plan_lowrank_stats(const nsgp_plan_t* P, int* n_lowrank, dou
     return NSGP_OK;
 }
 
+extern "C" int nsgp_plan_uses_split_mfma(const nsgp_plan_t* P) { return (P && P->use_x3) ? 1 : 0; }
+
+extern "C" size_t nsgp_split_projector_bytes(int D) { return D > 0 ? (size_t)D * D * 6 : 0; }
+
+extern "C" int nsgp_split_projector(const float* proj, int D, void* out, void* stream_) {
+    if (!proj || !out || D <= 0 || D % 8 != 0) return fail(NSGP_ERR_INVALID, "nsgp_split_projector: bad argument (D must be a multiple of 8)");
+    if (!aligned16(out)) return fail(NSGP_ERR_INVALID, "nsgp_split_projector: output must be 16-byte aligned");
+    hipLaunchKernelGGL(nsgp_split_transpose_bf16x3_kernel, dim3((D + 31) / 32, (D + 31) / 32), dim3(256), 0, static_cast<hipStream_t>(stream_),
+                       proj, D, D, static_cast<__bf16*>(out));
+    NSGP_LAUNCH_CHECK();
+    return NSGP_OK;
+}
+
 extern "C" int nsgp_plan_step(nsgp_plan_t* P, float* const* grads, const nsgp_hyper_t* hyper, int n_hyper,
                               void* stream_) {
     if (!P || !grads || !hyper) return fail(NSGP_ERR_INVALID, "nsgp_plan_step: null argument");
@@ -699,7 +722,12 @@ extern "C" int nsgp_plan_step(nsgp_plan_t* P, float* const* grads, const nsgp_hy
     NSGP_LAUNCH_CHECK();
     if (prof) NSGP_HIP(hipEventRecord(P->prof_ev[3 * P->prof_n + 1], stream));
     if (P->n_tiles_fast > 0) {
-        if (P->optimizer == NSGP_OPT_SGD)
+        if (P->use_x3) {
+            if (P->optimizer == NSGP_OPT_SGD)
+                hipLaunchKernelGGL((nsgp_project_kernel<NSGP_OPT_SGD, true, true>), dim3(P->n_tiles_fast), dim3(THREADS), X3_SMEM_BYTES, stream, P->d_tiles, P->d_layers, d);
+            else
+                hipLaunchKernelGGL((nsgp_project_kernel<NSGP_OPT_ADAM, true, true>), dim3(P->n_tiles_fast), dim3(THREADS), X3_SMEM_BYTES, stream, P->d_tiles, P->d_layers, d);
+        } else if (P->optimizer == NSGP_OPT_SGD)
             hipLaunchKernelGGL((nsgp_project_kernel<NSGP_OPT_SGD, true>), dim3(P->n_tiles_fast), dim3(THREADS), SMEM_BYTES, stream, P->d_tiles, P->d_layers, d);
         else
             hipLaunchKernelGGL((nsgp_project_kernel<NSGP_OPT_ADAM, true>), dim3(P->n_tiles_fast), dim3(THREADS), SMEM_BYTES, stream, P->d_tiles, P->d_layers, d);

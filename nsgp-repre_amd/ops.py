@@ -40,6 +40,18 @@ def project(a: torch.Tensor, proj: torch.Tensor, scale: float = 1.0, out: torch.
     return out
 
 
+def split_projector(P: torch.Tensor) -> torch.Tensor:
+    """Three-term bf16 split of ``P^T`` in the layout the split-MFMA projection streams ([n][k/8][term][8], 6 bytes per
+    element of P); ``sum of the terms == P`` to 24 mantissa bits.  One launch per projector per task."""
+    lib = _lib.load_library()
+    D = P.shape[0]
+    if P.shape != (D, D):
+        raise ValueError("projector must be square")
+    out = torch.empty(lib.nsgp_split_projector_bytes(D) // 2, dtype=torch.bfloat16, device=P.device)
+    _lib.check(lib.nsgp_split_projector(_dev(P, "P"), D, C.c_void_p(out.data_ptr()), _stream()), "nsgp_split_projector")
+    return out
+
+
 def build_projector(V: torch.Tensor, first_col: int, normalise: bool, out: torch.Tensor = None,
                     return_norm: bool = False):
     """``P = V[:, first_col:] @ V[:, first_col:].T`` (``/ ||P||_F`` if normalise) --

@@ -24,6 +24,9 @@ from .threshold import elbow_index
 
 logger = logging.getLogger("nsgp_repre_amd")
 
+#: default of ``optimizer.split_mfma`` (see NSCLOptimizerBase.__init__)
+SPLIT_MFMA_DEFAULT = False
+
 
 class NSCLOptimizerBase(Optimizer):
     _kind = _lib.NSGP_OPT_SGD   # which C-ABI update rule
@@ -42,6 +45,12 @@ class NSCLOptimizerBase(Optimizer):
         self.low_rank = False
         #: with low_rank: orthonormalise the eigenbasis (one Newton-Schulz step) before building P from it
         self.polish_basis = True
+        #: dense projection on the bf16 matrix cores: every fp32 operand split into three bf16 terms, six MFMAs per
+        #: fp32-equivalent product with fp32 accumulation (csrc/gemm_bf16x3.hpp).  Same error against fp64 as the fp32
+        #: MFMA path, ~1.35x its rate; costs 6 extra bytes per projector element for the split copy (made once per
+        #: projector, redone if the projector tensor is replaced or modified in place).  False = fp32 MFMA.
+        self.split_mfma = SPLIT_MFMA_DEFAULT
+        self._splits = {}
         self._basis = {}
         self._plans = []
         self._plan_key = None
@@ -58,6 +67,7 @@ class NSCLOptimizerBase(Optimizer):
         self._plans, self._plan_key, self._workspaces = [], None, []
         if not hasattr(self, "_basis"):
             self._basis, self.low_rank, self.mutate_grad, self.polish_basis = {}, False, True, True
+            self.split_mfma, self._splits = SPLIT_MFMA_DEFAULT, {}
 
     def __del__(self):
         try:
@@ -187,6 +197,8 @@ class NSCLOptimizerBase(Optimizer):
         """entries: list of (group_index, name, p, state).  One plan per <= NSGP_MAX_HYPER groups."""
         lib = _lib.load_library()
         self._destroy_plans()
+        live = {(P.data_ptr(), P._version) for P in self.transforms.values() if isinstance(P, torch.Tensor)}
+        self._splits = {k: v for k, v in self._splits.items() if k in live}      # drop splits of replaced projectors
         groups = sorted({gi for gi, *_ in entries})
         for lo in range(0, len(groups), _lib.NSGP_MAX_HYPER):
             gset = groups[lo:lo + _lib.NSGP_MAX_HYPER]
@@ -213,6 +225,8 @@ class NSCLOptimizerBase(Optimizer):
                                            f"{tuple(P.shape)} {P.dtype} {P.device}")
                     d.proj = P.data_ptr()
                     d.rows, d.cols = rows, cols
+                    if self.split_mfma and rows % 128 == 0 and cols % 128 == 0:
+                        d.proj_split = self._split_of(P).data_ptr()
                     b = self._basis.get(n)
                     if self.low_rank and b is not None and b["P_ptr"] == P.data_ptr() and b["V"].is_contiguous():
                         d.basis = b["V"].data_ptr()          # only for projectors this optimizer built itself
@@ -228,6 +242,20 @@ class NSCLOptimizerBase(Optimizer):
             self._workspaces.append(ws)
             self._plans.append(dict(handle=handle, entries=sub, groups=gset,
                                     grads=(C.c_void_p * len(sub))(), hyper=(_lib.Hyper * len(gset))()))
+
+    def _split_of(self, P: torch.Tensor) -> torch.Tensor:
+        """The three-term bf16 split of ``P^T`` (``nsgp_split_projector``), cached per (storage, version)."""
+        from .. import ops
+        k = (P.data_ptr(), P._version)
+        hit = self._splits.get(k)
+        if hit is None:
+            hit = self._splits[k] = ops.split_projector(P)
+        return hit
+
+    def uses_split_mfma(self) -> bool:
+        """True if every current plan runs its dense projection launch on the three-term bf16 split."""
+        lib = _lib.load_library()
+        return bool(self._plans) and all(lib.nsgp_plan_uses_split_mfma(p["handle"]) == 1 for p in self._plans)
 
     def plan_stats(self):
         """(gemm_flops, algorithmic_bytes, n_tiles, n_projected) summed over the current plans."""
@@ -290,14 +318,15 @@ class NSCLOptimizerBase(Optimizer):
                 loss = closure()
         lib = _lib.load_library()
         transforms, state = self.transforms, self.state
-        key = [bool(self.low_rank)]
+        key = [bool(self.low_rank), bool(self.split_mfma)]
         for gi, group in enumerate(self.param_groups):
             svd = group["svd"]
             for n, p in zip(group["names"], group["params"]):
                 P = transforms.get(n) if (svd and n in transforms) else None
                 # id(state dict): load_state_dict / a manual swap replaces the state tensors the plan points at
-                key.append((p.data_ptr(), gi, P.data_ptr() if isinstance(P, torch.Tensor) else 0, id(state[p])))
-        if len(key) == 1:
+                # P._version: an in-place edit of a projector invalidates its bf16 split
+                key.append((p.data_ptr(), gi, (P.data_ptr(), P._version) if isinstance(P, torch.Tensor) else 0, id(state[p])))
+        if len(key) == 2:
             return loss
         key = tuple(key)
         if key != self._plan_key:

@@ -276,10 +276,11 @@ def test_full_size_step_properties(N, dev):
     assert _rel(once, ref) <= 1e-5
 
 
-def test_full_r50_table_one_step_vs_torch_gpu(N, dev):
+@pytest.mark.parametrize("split", [False, True])
+def test_full_r50_table_one_step_vs_torch_gpu(N, dev, split):
     """The complete 50-layer R-50-FPN table (BASELINE configs[1]) in one plan: every
     projected parameter must equal p - lr*(buf @ P) computed layer by layer with torch on the
-    GPU; un-projected tensors plain SGD."""
+    GPU; un-projected tensors plain SGD.  Both MFMA paths: fp32 and the three-term bf16 split."""
     layers = O.resnet_fpn_projected_layers(50)
     gen = torch.Generator(device="cpu").manual_seed(7)
     params, names, Ps = [], [], {}
@@ -295,6 +296,7 @@ def test_full_r50_table_one_step_vs_torch_gpu(N, dev):
     opt.param_groups[0]["names"] = names
     for n, P in Ps.items():
         opt.transforms[n] = P
+    opt.split_mfma = split
     before = [p.detach().clone() for p in params]
     grads = [torch.randn(p.shape, generator=gen).to(dev) for p in params]
     for p, gr in zip(params, grads):
@@ -303,6 +305,7 @@ def test_full_r50_table_one_step_vs_torch_gpu(N, dev):
     torch.cuda.synchronize()
     flops, nbytes, ntiles, nproj = opt.plan_stats()
     assert nproj == 50 and abs(flops / 1e9 - 118.3) < 0.05 and ntiles == 1622
+    assert opt.uses_split_mfma() == split
     for n, p, p0, gr in zip(names, params, before, grads):
         d = gr + 1e-4 * p0
         upd = -(0.02 * d)
@@ -398,7 +401,7 @@ def test_low_rank_form_at_full_layer_size(N, dev):
 
 
 # ------------------------------------------------------------------ param groups, odd paths
-def _run_both(N, dev, groups_spec, shapes, transforms_cpu, steps=2, grad_views=None, kind="sgd"):
+def _run_both(N, dev, groups_spec, shapes, transforms_cpu, steps=2, grad_views=None, kind="sgd", split_mfma=None):
     """Run the HIP optimizer and the oracle on the same tensors; return (params_gpu, params_cpu)."""
     gen = torch.Generator().manual_seed(17)
     init = {n: torch.randn(s, generator=gen) * 0.05 for n, s in shapes.items()}
@@ -409,6 +412,8 @@ def _run_both(N, dev, groups_spec, shapes, transforms_cpu, steps=2, grad_views=N
         g["names"] = list(names)
     for n, P in transforms_cpu.items():
         opt.transforms[n] = P.to(dev)
+    if split_mfma is not None:
+        opt.split_mfma = split_mfma
     cpu = {n: init[n].clone() for n in shapes}
     states = {n: dict() for n in shapes}
     for step in range(steps):
@@ -454,6 +459,61 @@ def _proj_for(shapes, names):
         sv, V = O.eigens(torch.from_numpy(I.covariance_like(D, 70 + i, rows_mult=2)))
         tr[n] = O.build_projector(V, O.adaptive_threshold(sv, 0.0), "backbone" in n)
     return tr
+
+
+# ------------------------------------------------------------------ three-term bf16 split of the projection GEMM
+def test_split_projector_terms_sum_to_the_projector(N, dev):
+    from nsgp_repre_amd import ops
+    g = torch.Generator().manual_seed(3)
+    for D in (128, 256, 1152):
+        P = (torch.randn(D, D, generator=g) * torch.logspace(0, -6, D)[None, :]).to(dev)     # 6 decades of magnitudes
+        sp = ops.split_projector(P).view(D, D // 8, 3, 8).float()                            # [n][k/8][term][8]
+        terms = sp.permute(2, 0, 1, 3).reshape(3, D, D)                                        # [term][n][k]
+        back = (terms[0].double() + terms[1].double() + terms[2].double()).t()                 # [k][n] = P
+        err = (back - P.double()).abs()
+        assert (err <= 2.0 ** -23 * P.double().abs() + 1e-45).all()                            # 3 x 8 mantissa bits
+        assert (terms[1].abs() <= 2.0 ** -8 * terms[0].abs() + 1e-38).all()                    # each term is a residual of the last
+
+
+@pytest.mark.parametrize("kind", ["sgd", "adamw"])
+def test_split_mfma_steps_vs_oracle(N, dev, kind):
+    """The bf16x3 projection path against the CPU oracle under the same 1e-5 gate as the fp32 path: aligned layers run
+    the split kernel, a ragged layer in the same plan stays on the generic fp32 tiles, a plain tensor is untouched."""
+    shapes = {"backbone.a.weight": (128, 256), "backbone.b.weight": (256, 128, 3, 3), "neck.c.weight": (256, 256, 3, 3),
+              "backbone.ragged.weight": (100, 36, 3, 3), "rpn_head.x.weight": (64, 40)}
+    names = list(shapes)
+    tr = _proj_for(shapes, names[:4])
+    hp = dict(lr=0.02, momentum=0.9, weight_decay=1e-4) if kind == "sgd" else dict(lr=1e-3, weight_decay=0.05)
+    opt, params, cpu, init = _run_both(N, dev, [(names, hp)], shapes, tr, steps=3, kind=kind, split_mfma=True)
+    assert opt.uses_split_mfma()
+    _check(params, cpu, init, "split-" + kind)
+    # the same run on the fp32 MFMA path lands within the same gate of the split run
+    opt2, params2, cpu2, init2 = _run_both(N, dev, [(names, hp)], shapes, tr, steps=3, kind=kind, split_mfma=False)
+    assert not opt2.uses_split_mfma()
+    for n in shapes:
+        upd = (cpu[n] - init[n]).abs().max().item()
+        assert (params[n] - params2[n]).abs().max().item() <= REL * upd + 4 * 2.0 ** -23 * cpu[n].abs().max().item(), n
+
+
+def test_split_mfma_with_misaligned_gradients_and_projector_edits(N, dev):
+    """(i) gradient views at odd offsets: the split kernel's tile falls back to the guarded fp32 loader for that operand;
+    (ii) an in-place edit of a projector invalidates its cached split (tensor version in the plan key)."""
+    shapes = {"backbone.a.weight": (128, 256), "neck.c.weight": (256, 128, 3, 3)}
+    names = list(shapes)
+    tr = _proj_for(shapes, names)
+    hp = dict(lr=0.05, momentum=0.0, weight_decay=0.0)
+    opt, params, cpu, init = _run_both(N, dev, [(names, hp)], shapes, tr, steps=2, grad_views=True, split_mfma=True)
+    assert opt.uses_split_mfma()
+    _check(params, cpu, init, "split-misaligned")
+    n = names[0]
+    before = params[n].detach().clone()
+    opt.transforms[n].mul_(0.5)                                  # in place: same storage, new version
+    g = torch.randn(shapes[n], generator=torch.Generator().manual_seed(9))
+    for m in names:
+        params[m].grad = (g if m == n else torch.zeros(shapes[m])).to(dev)
+    opt.step()
+    want = before.cpu() + O.project_update(-(0.05 * g), 0.5 * tr[n])
+    assert _rel(params[n].detach() - before, want - before.cpu()) <= REL
 
 
 def test_param_groups_with_different_hyperparameters(N, dev):
@@ -511,7 +571,8 @@ def test_adamw_param_groups(N, dev):
 
 
 # ------------------------------------------------------------------ the other BASELINE configs as parity cases
-def test_r101_table_one_step_vs_torch_gpu(N, dev):
+@pytest.mark.parametrize("split", [False, True])
+def test_r101_table_one_step_vs_torch_gpu(N, dev, split):
     """configs[4] (R-101-FPN): 101 projected layers, 175.9 GFLOP, one plan."""
     layers = O.resnet_fpn_projected_layers(101)
     gen = torch.Generator(device="cpu").manual_seed(8)
@@ -527,6 +588,7 @@ def test_r101_table_one_step_vs_torch_gpu(N, dev):
     opt.param_groups[0]["names"] = names
     for n, P in Ps.items():
         opt.transforms[n] = P
+    opt.split_mfma = split
     before = [p.detach().clone() for p in params]
     grads = [torch.randn(p.shape, generator=gen).to(dev) for p in params]
     for p, gr in zip(params, grads):
@@ -534,7 +596,7 @@ def test_r101_table_one_step_vs_torch_gpu(N, dev):
     opt.step()
     torch.cuda.synchronize()
     flops, _, ntiles, nproj = opt.plan_stats()
-    assert nproj == 101 and abs(flops / 1e9 - 175.9) < 0.05 and ntiles == 2778
+    assert nproj == 101 and abs(flops / 1e9 - 175.9) < 0.05 and ntiles == 2778 and opt.uses_split_mfma() == split
     for n, p, p0, gr in zip(names, params, before, grads):
         upd = -(0.02 * (gr + 1e-4 * p0))
         exp = p0 + (upd.view(upd.shape[0], -1) @ Ps[n]).view_as(upd)
