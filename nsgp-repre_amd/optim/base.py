@@ -25,7 +25,7 @@ from .threshold import elbow_index
 logger = logging.getLogger("nsgp_repre_amd")
 
 #: default of ``optimizer.split_mfma`` (see NSCLOptimizerBase.__init__)
-SPLIT_MFMA_DEFAULT = False
+SPLIT_MFMA_DEFAULT = True
 
 
 class NSCLOptimizerBase(Optimizer):
