@@ -535,14 +535,26 @@ extern "C" int nsgp_plan_create(nsgp_plan_t** out, const nsgp_tensor_t* tensors,
             size_t g1 = g0;
             while (g1 < order.size() && ld[order[g1]].cols == ld[order[g0]].cols) ++g1;
             std::vector<TileDev> q[8];
-            int rot = 0;
+            // Panels go to the 8 queues in CONTIGUOUS runs of the group's panel list (layer after layer), balanced by
+            // tile count: an XCD then works on one or two layers of the group instead of all of them, so a layer's A
+            // operand is pulled into ~3 L2s instead of 8 (dealing the panels round-robin read every A once per XCD;
+            // measured 0.681 vs 0.695 ms on the split kernel, no change on the fp32 one).
+            long group_tiles = 0;
+            for (size_t oi = g0; oi < g1; ++oi) {
+                const int li = order[oi];
+                if ((layer_fast[li] != 0) != (pass == 0) || ld[li].rank > 0) continue;
+                group_tiles += (long)((ld[li].rows + BM - 1) / BM) * ((ld[li].cols + BN - 1) / BN);
+            }
+            long seen = 0;
             for (size_t oi = g0; oi < g1; ++oi) {
                 const int li = order[oi];
                 if ((layer_fast[li] != 0) != (pass == 0) || ld[li].rank > 0) continue;
                 const int mb = (ld[li].rows + BM - 1) / BM, nb = (ld[li].cols + BN - 1) / BN;
-                for (int j = 0; j < nb; ++j)
-                    for (int m = 0; m < mb; ++m) q[(j + rot) & 7].push_back(TileDev{li, m * BM, j * BN, 0});
-                rot += nb;
+                for (int j = 0; j < nb; ++j) {
+                    const int qi = (int)std::min<long>(7, seen * 8 / std::max<long>(group_tiles, 1));
+                    for (int m = 0; m < mb; ++m) q[qi].push_back(TileDev{li, m * BM, j * BN, 0});
+                    seen += mb;
+                }
             }
             size_t pos[8] = {0, 0, 0, 0, 0, 0, 0, 0};
             size_t total = 0;
