@@ -103,6 +103,9 @@ __device__ __forceinline__ void x3_terms(const X3Frags& f, f32x16 (&acc)[2][2]) 
 // Pipeline: two LDS stages + three register sets.  In step t (stage t&1 holds k-chunk t): 8 MFMAs | split + write the A
 // part of chunk t+1 into the other stage | 8 MFMAs | write its B part, refill that register set with chunk t+4 |
 // 8 MFMAs | barrier.  A load is consumed three steps (~2 us) after it is issued.
+// ABLATE (tools/bf16x3_bench.hip only; results are garbage for != 0): 1 = no global loads inside the loop, 2 = also no
+// split / LDS writes, 3 = also no barrier.
+template <int ABLATE = 0>
 __device__ __forceinline__ void gemm_tile_bf16x3(const float* __restrict__ A, long lda, const __bf16* __restrict__ Bt, int K,
                                                  int m0, int n0, float* smem_f, f32x16 (&acc)[2][2]) {
     __bf16* smem = reinterpret_cast<__bf16*>(smem_f);
@@ -127,14 +130,14 @@ __device__ __forceinline__ void gemm_tile_bf16x3(const float* __restrict__ A, lo
         x3_read(cur, wm, wn, f);
         x3_terms<0>(f, acc);
         __builtin_amdgcn_sched_barrier(SCHED_PIN_STAGING);
-        x3_write_a(nxt, regs[S]);
+        if (ABLATE < 2) x3_write_a(nxt, regs[S]);
         x3_terms<1>(f, acc);
         __builtin_amdgcn_sched_barrier(SCHED_PIN_STAGING);
-        x3_write_b(nxt, regs[S]);
-        x3_load(pa, pb, (long)min(kt + 4, last) * X3_BK, regs[S]);
+        if (ABLATE < 2) x3_write_b(nxt, regs[S]);
+        if (ABLATE < 1) x3_load(pa, pb, (long)min(kt + 4, last) * X3_BK, regs[S]);
         __builtin_amdgcn_sched_barrier(SCHED_PIN_VMEM_READ);
         x3_terms<2>(f, acc);
-        __syncthreads();
+        if (ABLATE < 3) __syncthreads();
     };
     int kt = 0;
     for (; kt + 5 < nk; kt += 6) {

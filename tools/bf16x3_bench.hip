@@ -79,6 +79,108 @@ static float run(const __bf16* src, float* C, int M, int N, int K) {
 
 // ---- full data path: gemm_tile_bf16x3 against the production fp32 tile ------------------------------------------------
 #include "gemm_bf16x3.hpp"
+namespace nsgp {
+// EXPERIMENT (measured, not adopted -- DESIGN.md section 4): bit-identical to the 128 x 128 split tile, 205 vs 190 TF-eq on
+// 4096^3; with one 8-wave workgroup per CU the R-50 table would be ~800 tiles on 256 slots and the scheduling tail costs more.
+// ---- 256 x 128 tile, 8 waves (512 threads), one workgroup per CU ---------------------------------------------------
+// The 128 x 128 tile is bound by the L2 -> CU path (tools/bf16x3_bench.hip: 186 TF-eq, 241 with the global loads removed):
+// per step it pulls 8 KB of A and 12 KB of B for 24 MFMAs per wave.  B -- 96 B per row and step, the expensive operand --
+// is shared here by twice as many rows: 16 + 12 = 28 KB for TWICE the MFMAs (14 KB per 128 x 128 instead of 20).
+// Waves 4 x 2, each 64 x 64 as before; A image 256 rows, B image 128 rows; thread t stages A pair (row t>>1, octet t&1),
+// threads 0-255 the B terms 0 and 1 of pair t, threads 256-511 term 2 of pair t-256.
+constexpr int X3W_OCT_A = 256 * 8 + 32;
+constexpr int X3W_PLANE_A = 2 * X3W_OCT_A, X3W_PLANE_B = X3_PLANE;
+constexpr int X3W_STAGE = 3 * X3W_PLANE_A + 3 * X3W_PLANE_B;          // bf16 elements (37,632 B)
+constexpr int X3W_EPI_BYTES = 8 * 64 * EPI_LD * 4;                     // 8 waves park 64 x 64 fp32 each: 128 KB
+constexpr int X3W_SMEM_BYTES = (2 * X3W_STAGE * 2 > X3W_EPI_BYTES) ? 2 * X3W_STAGE * 2 : X3W_EPI_BYTES;
+
+struct X3WRegs {
+    f32x4 a[2];
+    bf16x8 b[2];
+};
+
+template <int ABLATE = 0>
+__device__ __forceinline__ void gemm_tile_bf16x3_256(const float* __restrict__ A, long lda, const __bf16* __restrict__ Bt, int K,
+                                                     int m0, int n0, float* smem_f, f32x16 (&acc)[2][2]) {
+    __bf16* smem = reinterpret_cast<__bf16*>(smem_f);
+    const int t = threadIdx.x, wave = t >> 6, lane = t & 63;
+    const int wm = wave >> 1, wn = wave & 1;                   // 4 x 2 waves
+    const bool lo = t < 256;                                   // wave-uniform: which B terms this thread stages
+    const int bp = lo ? t : t - 256;                           // B (row, octet) pair
+    const float* pa = A + (long)(m0 + (t >> 1)) * lda + (t & 1) * 8;
+    const __bf16* pb = Bt + (long)(n0 + (bp >> 1)) * K * 3 + (bp & 1) * 24 + (lo ? 0 : 16);
+    const int a_slot = (t & 1) * X3W_OCT_A + (t >> 1) * 8;
+    const int b_slot = 3 * X3W_PLANE_A + (lo ? 0 : 2) * X3W_PLANE_B + (bp & 1) * X3_OCT + (bp >> 1) * 8;
+    const int nk = K / X3_BK, last = nk - 1;
+    auto load = [&](long k0, X3WRegs& r) {
+        r.a[0] = *(const gf32x4*)(pa + k0);
+        r.a[1] = *(const gf32x4*)(pa + k0 + 4);
+        r.b[0] = *(const g_bf16x8*)(pb + 3 * k0);
+        if (lo) r.b[1] = *(const g_bf16x8*)(pb + 3 * k0 + 8);
+    };
+    auto write_a = [&](__bf16* stage, const X3WRegs& r) {
+        bf16x8 p0, p1, p2;
+        x3_split(r.a[0], r.a[1], p0, p1, p2);
+        *reinterpret_cast<bf16x8*>(stage + 0 * X3W_PLANE_A + a_slot) = p0;
+        *reinterpret_cast<bf16x8*>(stage + 1 * X3W_PLANE_A + a_slot) = p1;
+        *reinterpret_cast<bf16x8*>(stage + 2 * X3W_PLANE_A + a_slot) = p2;
+    };
+    auto write_b = [&](__bf16* stage, const X3WRegs& r) {
+        *reinterpret_cast<bf16x8*>(stage + b_slot) = r.b[0];
+        if (lo) *reinterpret_cast<bf16x8*>(stage + b_slot + X3W_PLANE_B) = r.b[1];
+    };
+    auto read = [&](const __bf16* stage, X3Frags& f) {
+        const int r = lane & 31, h = lane >> 5;
+#pragma unroll
+        for (int p = 0; p < 3; ++p)
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                f.a[i][p] = *reinterpret_cast<const bf16x8*>(stage + p * X3W_PLANE_A + h * X3W_OCT_A + (wm * 64 + i * 32 + r) * 8);
+                f.b[i][p] = *reinterpret_cast<const bf16x8*>(stage + 3 * X3W_PLANE_A + p * X3W_PLANE_B + h * X3_OCT + (wn * 64 + i * 32 + r) * 8);
+            }
+    };
+    X3WRegs regs[3];
+    load(0, regs[0]);
+    load((long)min(1, last) * X3_BK, regs[1]);
+    load((long)min(2, last) * X3_BK, regs[2]);
+    write_a(smem, regs[0]);
+    write_b(smem, regs[0]);
+    load((long)min(3, last) * X3_BK, regs[0]);
+    __syncthreads();
+    auto step = [&](int kt, auto rb, auto s) {
+        constexpr int RB = decltype(rb)::value, S = decltype(s)::value;
+        const __bf16* cur = smem + RB * X3W_STAGE;
+        __bf16* nxt = smem + (1 - RB) * X3W_STAGE;
+        X3Frags f;
+        read(cur, f);
+        x3_terms<0>(f, acc);
+        __builtin_amdgcn_sched_barrier(SCHED_PIN_STAGING);
+        if (ABLATE < 2) write_a(nxt, regs[S]);
+        x3_terms<1>(f, acc);
+        __builtin_amdgcn_sched_barrier(SCHED_PIN_STAGING);
+        if (ABLATE < 2) write_b(nxt, regs[S]);
+        if (ABLATE < 1) load((long)min(kt + 4, last) * X3_BK, regs[S]);
+        __builtin_amdgcn_sched_barrier(SCHED_PIN_VMEM_READ);
+        x3_terms<2>(f, acc);
+        if (ABLATE < 3) __syncthreads();
+    };
+    int kt = 0;
+    for (; kt + 5 < nk; kt += 6) {
+        step(kt, IC<0>{}, IC<1>{});
+        step(kt + 1, IC<1>{}, IC<2>{});
+        step(kt + 2, IC<0>{}, IC<0>{});
+        step(kt + 3, IC<1>{}, IC<1>{});
+        step(kt + 4, IC<0>{}, IC<2>{});
+        step(kt + 5, IC<1>{}, IC<0>{});
+    }
+    if (kt < nk) { step(kt, IC<0>{}, IC<1>{}); ++kt; }
+    if (kt < nk) { step(kt, IC<1>{}, IC<2>{}); ++kt; }
+    if (kt < nk) { step(kt, IC<0>{}, IC<0>{}); ++kt; }
+    if (kt < nk) { step(kt, IC<1>{}, IC<1>{}); ++kt; }
+    if (kt < nk) { step(kt, IC<0>{}, IC<2>{}); ++kt; }
+}
+
+}  // namespace nsgp
 using namespace nsgp;
 
 __device__ __forceinline__ void store_plain(float* C, int N, int m0, int n0, const f32x16 (&acc)[2][2]) {
@@ -87,13 +189,27 @@ __device__ __forceinline__ void store_plain(float* C, int N, int m0, int n0, con
         C[(long)(m0 + wm * 64 + mi * 32 + acc_row(e, lane)) * N + n0 + wn * 64 + ni * 32 + (lane & 31)] = acc[mi][ni][e];
 }
 
-__global__ __launch_bounds__(256, 2) void x3_kernel(const float* __restrict__ A, const __bf16* __restrict__ Bt, float* __restrict__ C, int M, int N, int K) {
+template <int ABL = 0>
+__global__ __launch_bounds__(256, 2) void x3_kernel_t(const float* __restrict__ A, const __bf16* __restrict__ Bt, float* __restrict__ C, int M, int N, int K) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
     f32x16 acc[2][2];
     zero_acc(acc);
     const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
-    gemm_tile_bf16x3(A, K, Bt, K, m0, n0, sm, acc);
+    gemm_tile_bf16x3<ABL>(A, K, Bt, K, m0, n0, sm, acc);
     store_plain(C, N, m0, n0, acc);
+}
+#define x3_kernel x3_kernel_t<0>
+
+template <int ABL = 0>
+__global__ __launch_bounds__(512, 1) void x3w_kernel(const float* __restrict__ A, const __bf16* __restrict__ Bt, float* __restrict__ C, int M, int N, int K) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    f32x16 acc[2][2];
+    zero_acc(acc);
+    const int m0 = blockIdx.y * 256, n0 = blockIdx.x * BN;
+    gemm_tile_bf16x3_256<ABL>(A, K, Bt, K, m0, n0, sm, acc);
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, wm = wave >> 1, wn = wave & 1;
+    for (int mi = 0; mi < 2; ++mi) for (int ni = 0; ni < 2; ++ni) for (int e = 0; e < 16; ++e)
+        C[(long)(m0 + wm * 64 + mi * 32 + acc_row(e, lane)) * N + n0 + wn * 64 + ni * 32 + (lane & 31)] = acc[mi][ni][e];
 }
 __global__ __launch_bounds__(256, 2) void f32_kernel(const float* __restrict__ A, const float* __restrict__ B, float* __restrict__ C, int M, int N, int K) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
@@ -127,11 +243,35 @@ static int full_path(int M, int N, int K) {
     for (auto& v : ha) v = rnd() * 1e-3f;
     for (auto& v : hb) v = rnd() * 0.05f;
     (void)hipMemcpy(A, ha.data(), ha.size() * 4, hipMemcpyHostToDevice); (void)hipMemcpy(B, hb.data(), hb.size() * 4, hipMemcpyHostToDevice);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(x3_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, X3_SMEM_BYTES);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(x3_kernel_t<0>), hipFuncAttributeMaxDynamicSharedMemorySize, X3_SMEM_BYTES);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(f32_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, SMEM_BYTES);
     const float t_split = time_it([&] { hipLaunchKernelGGL(nsgp_split_transpose_bf16x3_kernel, dim3((N + 31) / 32, (K + 31) / 32), dim3(256), 0, 0, B, K, N, Bt); });
     const float t0 = time_it([&] { hipLaunchKernelGGL(f32_kernel, dim3(N / BN, M / BM), dim3(256), SMEM_BYTES, 0, A, B, C0, M, N, K); });
     const float t1 = time_it([&] { hipLaunchKernelGGL(x3_kernel, dim3(N / BN, M / BM), dim3(256), X3_SMEM_BYTES, 0, A, Bt, C1, M, N, K); });
+    if (M % 256 == 0) {  // the 256 x 128 / 8-wave tile: correctness against the 128 x 128 split tile, then timing
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(x3w_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, X3W_SMEM_BYTES);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(x3w_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, X3W_SMEM_BYTES);
+        float* C2; (void)hipMalloc(&C2, (size_t)M * N * 4);
+        const float tw = time_it([&] { hipLaunchKernelGGL(x3w_kernel<0>, dim3(N / BN, M / 256), dim3(512), X3W_SMEM_BYTES, 0, A, Bt, C2, M, N, K); });
+        const float tw1 = time_it([&] { hipLaunchKernelGGL(x3w_kernel<1>, dim3(N / BN, M / 256), dim3(512), X3W_SMEM_BYTES, 0, A, Bt, C0, M, N, K); });
+        hipLaunchKernelGGL(x3w_kernel<0>, dim3(N / BN, M / 256), dim3(512), X3W_SMEM_BYTES, 0, A, Bt, C2, M, N, K);
+        std::vector<float> c1h((size_t)M * N), c2h((size_t)M * N);
+        (void)hipMemcpy(c1h.data(), C1, c1h.size() * 4, hipMemcpyDeviceToHost); (void)hipMemcpy(c2h.data(), C2, c2h.size() * 4, hipMemcpyDeviceToHost);
+        double dmw = 0; for (size_t i = 0; i < c1h.size(); ++i) dmw = std::max(dmw, (double)fabsf(c1h[i] - c2h[i]));
+        const double fl_ = 2.0 * M * N * (double)K;
+        printf("   256x128 tile: %.3f ms %.1f TF-eq (no global loads: %.1f)   max|diff| vs 128x128 split tile %.3g\n", tw, fl_ / tw / 1e9, fl_ / tw1 / 1e9, dmw);
+        (void)hipFree(C2);
+    }
+    if (M == 4096) {     // ablation of the full tile (timing only)
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(x3_kernel_t<1>), hipFuncAttributeMaxDynamicSharedMemorySize, X3_SMEM_BYTES);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(x3_kernel_t<2>), hipFuncAttributeMaxDynamicSharedMemorySize, X3_SMEM_BYTES);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(x3_kernel_t<3>), hipFuncAttributeMaxDynamicSharedMemorySize, X3_SMEM_BYTES);
+        const double fl_ = 2.0 * M * N * (double)K;
+        const float a1 = time_it([&] { hipLaunchKernelGGL(x3_kernel_t<1>, dim3(N / BN, M / BM), dim3(256), X3_SMEM_BYTES, 0, A, Bt, C0, M, N, K); });
+        const float a2 = time_it([&] { hipLaunchKernelGGL(x3_kernel_t<2>, dim3(N / BN, M / BM), dim3(256), X3_SMEM_BYTES, 0, A, Bt, C0, M, N, K); });
+        const float a3 = time_it([&] { hipLaunchKernelGGL(x3_kernel_t<3>, dim3(N / BN, M / BM), dim3(256), X3_SMEM_BYTES, 0, A, Bt, C0, M, N, K); });
+        printf("   ablation: full %.1f | no global loads %.1f | + no split/LDS writes %.1f | + no barrier %.1f  TF-eq\n", fl_ / t1 / 1e9, fl_ / a1 / 1e9, fl_ / a2 / 1e9, fl_ / a3 / 1e9);
+    }
     std::vector<float> c0((size_t)M * N), c1((size_t)M * N);
     (void)hipMemcpy(c0.data(), C0, c0.size() * 4, hipMemcpyDeviceToHost); (void)hipMemcpy(c1.data(), C1, c1.size() * 4, hipMemcpyDeviceToHost);
     // fp64 reference on a sample of entries
