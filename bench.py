@@ -312,6 +312,8 @@ def end_to_end_training(N, dev, world, local_rank, basis_cache, steps, warmup, a
            "parallelism": f"DDP x{world}: bucketed RCCL all-reduce of the gradients overlapped with backward" if world > 1 else "single",
            "detector": "nsgp_repre_amd.detection (R-50-FPN Faster R-CNN, stock recipe in plain PyTorch-ROCm: MIOpen convolutions, "
                        "hipBLASLt GEMMs; teacher predict + pseudo-label filter every step, as det:65-109)"}
+    if graphs:
+        model.disable_graphs()
     del net, model, opt
     torch.cuda.empty_cache()
     return out

@@ -38,6 +38,7 @@ class GraphedTrunk:
         self.shape, self.train = tuple(sample.shape), train
         self.amp_dtype = amp_dtype
         trunk = ConvTrunk(model.backbone, model.neck, model.rpn_head)
+        self._trunk = trunk
         if train:
             trunk.train()
             with self._autocast():
@@ -57,6 +58,18 @@ class GraphedTrunk:
 
     def _autocast(self):
         return torch.autocast("cuda", dtype=self.amp_dtype or torch.bfloat16, enabled=self.amp_dtype is not None, cache_enabled=False)
+
+    def close(self):
+        """Drop the captured graphs NOW.  ``make_graphed_callables`` leaves a reference cycle (module -> patched forward
+        -> module), so without this the graphs and their private memory pool are torn down whenever the garbage collector
+        happens to run -- possibly on another thread in the middle of unrelated GPU work."""
+        trunk = getattr(self, "_trunk", None)
+        if trunk is not None and "forward" in trunk.__dict__:
+            del trunk.__dict__["forward"]                     # restores the class's forward, breaks the cycle
+        for name in ("fn", "graph", "static_in", "static_out", "_trunk"):
+            if hasattr(self, name):
+                delattr(self, name)
+        torch.cuda.synchronize()
 
     def matches(self, x) -> bool:
         return tuple(x.shape) == self.shape and x.is_cuda

@@ -81,6 +81,13 @@ class FasterRCNNRoIReplay(RoIReplayModes, _Base):
                 t = self.teacher_model
                 object.__setattr__(t, "_graph_eval", GraphedTrunk(t, sample_input, False, amp_dtype))
 
+        def disable_graphs(self):
+            """Release the captured graphs deterministically (see ``GraphedTrunk.close``)."""
+            for owner, name in ((self, "_graph_train"), (getattr(self, "teacher_model", None), "_graph_eval")):
+                g = owner.__dict__.pop(name, None) if owner is not None else None
+                if g is not None:
+                    g.close()
+
         def _trunk(self, batch_inputs):
             """(feats, precomputed RPN maps or None): graph replay when one was captured for this mode and shape."""
             g = getattr(self, "_graph_train", None) if (self.training and torch.is_grad_enabled()) else getattr(self, "_graph_eval", None)

@@ -132,6 +132,13 @@ def test_graphed_trunk_matches_eager(N, dev):
         model(x, copy.deepcopy(samples), mode="nullspace")
     h.remove()
     assert fired
+    # release the graphs here and now, not whenever the garbage collector gets to the cycle make_graphed_callables leaves
+    model.disable_graphs()
+    assert "_graph_train" not in model.__dict__ and "_graph_eval" not in model.teacher_model.__dict__
+    del model
+    import gc
+    gc.collect()
+    torch.cuda.synchronize()
 
 
 def _rel(a, b):

@@ -18,7 +18,10 @@ def main():
     ap.add_argument("--batch", type=int, default=1)
     ap.add_argument("--channels-last", action="store_true")
     ap.add_argument("--graphs", action="store_true")
+    ap.add_argument("--miopen-find", action="store_true", help="torch.backends.cudnn.benchmark = True: MIOpen searches for the fastest solver per convolution")
     args = ap.parse_args()
+    if args.miopen_find:
+        torch.backends.cudnn.benchmark = True
     import nsgp_repre_amd as N
     torch.cuda.set_device(0)
     dev = torch.device("cuda", 0)
