@@ -51,7 +51,7 @@ int nsgp_device_arch(char* buf, int buflen);
  *   SGDNSCLNA.step    mmdet/engine/optimizers/SGD_NSCL_NoAdaptive.py:59-111
  * by two launches: one multi-tensor elementwise kernel over every listed
  * tensor (momentum / Adam moments / weight decay, `p += update` for the
- * un-projected ones) and one grouped fp32-MFMA GEMM `p += update.view(Cout,D) @ P`
+ * un-projected ones) and one grouped MFMA GEMM `p += update.view(Cout,D) @ P`
  * over every projected tensor (the `torch.mm(update.view(Cout,-1), P)` of
  * SGD_NSCL.py:85-90).
  * ------------------------------------------------------------------------ */

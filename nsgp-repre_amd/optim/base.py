@@ -8,8 +8,9 @@ the public ``eigens`` / ``transforms`` dicts and the extra param-group key
 
 What differs is *how* a step runs: instead of a Python loop of ~160 x 5 tiny
 elementwise launches plus 50 `torch.mm`, ``step()`` hands one table to
-``nsgp_plan_step`` (C ABI): one multi-tensor HIP kernel + one grouped fp32-MFMA
-GEMM on the current stream.
+``nsgp_plan_step`` (C ABI): one multi-tensor HIP kernel + one grouped MFMA GEMM
+(three-term bf16 split by default, fp32 MFMA with ``split_mfma = False``) on the
+current stream.
 """
 import ctypes as C
 import logging
