@@ -198,9 +198,9 @@ PEAK_BF16_MATRIX_TFLOPS = 2500.0   # dense bf16 MFMA peak (MI355X_MICROARCH.md)
 
 
 def roofline_block(split, flops, abytes, gemm_ms, update_ms, nsgp_ms, n_prof, numel, ntiles, nproj):
-    """`roofline` for the dominant kernel.  The algorithm is an fp32 contraction of 118.3 GFLOP.  On the split path
-    every fp32 product is evaluated as six bf16 MFMA products (fp32-accurate), so the matrix cores
-    EXECUTE 6 x the algorithmic FLOPs: `achieved`/`peak`/`frac` are executed bf16 FLOP/s against the dense bf16 peak (a
+    """`roofline` for the dominant kernel.  The algorithm is an fp32 contraction of 118.3 GFLOP.  On the split paths
+    every fp32 product is evaluated as three fp16 (or six bf16) MFMA products (fp32-accurate), so the
+    matrix cores EXECUTE 3 x (6 x) the algorithmic FLOPs: `achieved`/`peak`/`frac` are executed bf16 FLOP/s against the dense bf16 peak (a
     true utilisation, <= 1), and the fp32-equivalent rate against the fp32 matrix peak is given beside it."""
     alg_tf = flops / (gemm_ms * 1e-3) / 1e12
     common = {"kernel_ms": gemm_ms, "elementwise_kernel_ms": update_ms, "profiled_steps": n_prof, "algorithmic_flops": flops,
@@ -209,10 +209,13 @@ def roofline_block(split, flops, abytes, gemm_ms, update_ms, nsgp_ms, n_prof, nu
               "traffic": None, "algorithmic_fp32_equivalent_tflops": alg_tf,
               "vs_fp32_matrix_peak": alg_tf / PEAK_FP32_MATRIX_TFLOPS}
     if split:
-        return {"bound": "mfma", "kernel": "nsgp_project_kernel<SGD,fast,bf16x3>", "achieved": 6 * alg_tf, "peak": PEAK_BF16_MATRIX_TFLOPS,
-                "unit": "TFLOP/s", "frac": 6 * alg_tf / PEAK_BF16_MATRIX_TFLOPS, "executed_flops_per_algorithmic_flop": 6,
-                "note": "six v_mfma_f32_32x32x16_bf16 per fp32-equivalent product (3-term bf16 split of both operands, fp32 accumulation); "
-                        "the same kernel's ceiling with operands already in LDS measured 1.5 PFLOP/s on non-zero data (tools/bf16x3_bench.hip)",
+        mult = {"bf16x3": 6, "f16x2": 3}[split]
+        return {"bound": "mfma", "kernel": f"nsgp_project_kernel<SGD,fast,{split}>", "achieved": mult * alg_tf, "peak": PEAK_BF16_MATRIX_TFLOPS,
+                "unit": "TFLOP/s", "frac": mult * alg_tf / PEAK_BF16_MATRIX_TFLOPS, "executed_flops_per_algorithmic_flop": mult,
+                "note": ("three v_mfma_f32_32x32x16_f16 per fp32-equivalent product (2-term fp16 split of both operands, one power-of-two "
+                         "scale per operand matrix, fp32 accumulation)" if split == "f16x2" else
+                         "six v_mfma_f32_32x32x16_bf16 per fp32-equivalent product (3-term bf16 split of both operands, fp32 accumulation)")
+                        + "; peak = dense 16-bit MFMA peak",
                 **common}
     return {"bound": "mfma", "kernel": "nsgp_project_kernel<SGD,fast>", "achieved": alg_tf, "peak": PEAK_FP32_MATRIX_TFLOPS, "unit": "TFLOP/s",
             "frac": alg_tf / PEAK_FP32_MATRIX_TFLOPS, "executed_flops_per_algorithmic_flop": 1, **common}
@@ -464,8 +467,9 @@ def main():
             "nsgp_step_ms": nsgp_ms,
             "host_ms_in_optimizer_step": 1e3 * sum(host_step[-args.steps:]) / max(1, len(host_step[-args.steps:])),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32 (parameters, gradients, state, accumulation; the projection's products as 3-term bf16 splits on the matrix cores)"
-                     if opt.uses_split_mfma() else "f32", "data": "synthetic",
+            "dtype": {"f16x2": "f32 (parameters, gradients, state, accumulation; the projection's products as 2-term fp16 splits on the matrix cores)",
+                      "bf16x3": "f32 (parameters, gradients, state, accumulation; the projection's products as 3-term bf16 splits on the matrix cores)"
+                      }.get(opt.uses_split_mfma(), "f32"), "data": "synthetic",
             "config": {"workload": "R-50-FPN VOC 15+5 task 2 (configs[1]): SGDNSCL step over 50 projected layers "
                                    "+ 112 plain tensors (41.2M params), replay loss on K=150 prototypes, 1 img/GPU/step",
                        "autocast": "bf16 for the replay head's GEMMs (as tools/train.py --amp does for the detector); parameters, gradients, optimizer state and the whole NSGP step fp32" if args.amp else "off",
@@ -475,24 +479,28 @@ def main():
         }
         # opt-in low-rank form of the same projectors (north_star: g - U(U^T g)); timed separately so that
         # the headline numbers above stay those of the dense parity path
-        if world == 1:      # the other MFMA path of the same dense step, timed separately
-            other = not opt.split_mfma
-            opt.split_mfma = other
-            for _ in range(3):
-                one_step()
-            torch.cuda.synchronize()
-            opt.profile_begin(args.steps)
-            t1 = time.perf_counter()
-            for _ in range(args.steps):
-                one_step()
-            torch.cuda.synchronize()
-            o_elapsed = (time.perf_counter() - t1) / args.steps * 1e3
-            _, o_update_ms, o_gemm_ms = opt.profile_end()
-            out["other_mfma_path"] = {"path": "bf16x3 split (six bf16 MFMAs per fp32-equivalent product)" if other else "fp32 MFMA (v_mfma_f32_32x32x2_f32)",
-                                      "uses_split_mfma": opt.uses_split_mfma(), "ms_per_step": o_elapsed, "nsgp_step_ms": o_update_ms + o_gemm_ms,
-                                      "projection_kernel_ms": o_gemm_ms, "fp32_equivalent_tflops": flops / (o_gemm_ms * 1e-3) / 1e12,
-                                      "frac_of_fp32_matrix_peak": flops / (o_gemm_ms * 1e-3) / 1e12 / PEAK_FP32_MATRIX_TFLOPS}
-            opt.split_mfma = not other
+        if world == 1:      # the other MFMA paths of the same dense step, timed separately
+            default_path = opt.split_mfma
+            out["other_mfma_paths"] = {}
+            for other in ("f16x2", "bf16x3", False):
+                if other == opt.uses_split_mfma():
+                    continue
+                opt.split_mfma = other
+                for _ in range(3):
+                    one_step()
+                torch.cuda.synchronize()
+                opt.profile_begin(args.steps)
+                t1 = time.perf_counter()
+                for _ in range(args.steps):
+                    one_step()
+                torch.cuda.synchronize()
+                o_elapsed = (time.perf_counter() - t1) / args.steps * 1e3
+                _, o_update_ms, o_gemm_ms = opt.profile_end()
+                out["other_mfma_paths"][other or "f32"] = {
+                    "uses_split_mfma": opt.uses_split_mfma(), "ms_per_step": o_elapsed, "nsgp_step_ms": o_update_ms + o_gemm_ms,
+                    "projection_kernel_ms": o_gemm_ms, "fp32_equivalent_tflops": flops / (o_gemm_ms * 1e-3) / 1e12,
+                    "frac_of_fp32_matrix_peak": flops / (o_gemm_ms * 1e-3) / 1e12 / PEAK_FP32_MATRIX_TFLOPS}
+            opt.split_mfma = default_path
         if world == 1:
             opt.low_rank = True
             for _ in range(3):

@@ -32,7 +32,7 @@ extern "C" {
 #define NSGP_ERR_WORKSPACE (-3) /* workspace too small */
 #define NSGP_ERR_LIMIT (-4)     /* a fixed capacity was exceeded (e.g. > NSGP_MAX_HYPER combos) */
 
-#define NSGP_ABI_VERSION 4
+#define NSGP_ABI_VERSION 5
 #define NSGP_MAX_HYPER 32 /* distinct hyper-parameter sets per plan step */
 
 int nsgp_abi_version(void);
@@ -78,11 +78,15 @@ typedef struct {
                            p += basis_scale * (u - (u U) U^T),  U = V[:, :rank]  ==  u @ (basis_scale * V_tail V_tail^T)
                            in 4*Cout*D*r FLOP instead of 2*Cout*D^2; otherwise the dense `proj` is used */
     float basis_scale;  /* 1/||P||_F for Frobenius-normalised projectors (SGD_NSCL.py:282-283), else 1 */
+    int32_t split_kind; /* 0: no split copy; 1: proj_split holds the three-term bf16 split (nsgp_split_projector);
+                           2: the two-term fp16 split of split_scale * proj (nsgp_split_projector_f16) */
+    const void* proj_split; /* optional split copy of proj^T.  When every 128-aligned projected tensor of a plan carries one
+                           of the same kind, the dense projection runs on the low-precision matrix cores with fp32 accumulation
+                           and fp32-level error: kind 1 = six bf16 MFMAs per product (a0b0+a0b1+a1b0+a0b2+a1b1+a2b0),
+                           kind 2 = three fp16 MFMAs per product (a0b0+a0b1+a1b0) with one power-of-two scale per operand
+                           matrix (the update's is found by the elementwise launch of the same step).  NULL = fp32 MFMA */
+    float split_scale;  /* kind 2: the power of two proj was multiplied by before the split (largest |entry| in [2^13, 2^14)) */
     int32_t reserved;
-    const void* proj_split; /* optional: the three-term bf16 split of proj^T written by nsgp_split_projector.  When every
-                           128-aligned projected tensor of a plan carries one, the dense projection runs on the bf16 matrix
-                           cores as six MFMAs per fp32-equivalent product (a0b0+a0b1+a1b0+a0b2+a1b1+a2b0, fp32
-                           accumulation; error vs fp64 equal to the fp32-MFMA path's).  NULL = fp32 MFMA */
 } nsgp_tensor_t;
 
 /* Per-step hyper-parameters of one param group (host values, fp64->fp32 as torch does). */
@@ -126,7 +130,7 @@ int nsgp_plan_stats(const nsgp_plan_t* plan, double* gemm_flops, double* algorit
 /* Layers that take the low-rank form and their FLOPs (sum 4*Cout*D*r), tile counts of its two phases. */
 int nsgp_plan_lowrank_stats(const nsgp_plan_t* plan, int* n_lowrank, double* lowrank_flops,
                             int* n_tiles_p1, int* n_tiles_p2);
-/* 1 if the plan's dense projection launch uses the three-term bf16 split (every fast tensor carried proj_split). */
+/* Kind of split the plan's dense projection launch uses: 0 = fp32 MFMA, 1 = three-term bf16, 2 = two-term fp16. */
 int nsgp_plan_uses_split_mfma(const nsgp_plan_t* plan);
 
 /* Per-launch timing with HIP events recorded on the launch stream (measurement only): between
@@ -140,6 +144,10 @@ int nsgp_plan_profile_end(nsgp_plan_t* plan, int* n_steps, float* update_ms_avg,
  * proj: [D x D] fp32 row-major; out: >= nsgp_split_projector_bytes(D) bytes, 16-byte aligned; D % 8 == 0. */
 size_t nsgp_split_projector_bytes(int D);
 int nsgp_split_projector(const float* proj, int D, void* out, void* stream);
+/* Two-term fp16 split of scale * proj^T, layout [n][k/8][term][8] fp16, 4 bytes per element.  `scale` must be a power of two
+ * that brings the largest |entry| of proj below 2^14 (fp16 overflows at 65504); the caller keeps it in split_scale. */
+size_t nsgp_split_projector_f16_bytes(int D);
+int nsgp_split_projector_f16(const float* proj, int D, float scale, void* out, void* stream);
 
 /* Stand-alone projection `out[rows x cols] (+)= scale * (a[rows x cols] @ proj[cols x cols])`
  * (SGD_NSCL.py:85-90 in isolation; accumulate=0 overwrites `out`).  Used by tests to check

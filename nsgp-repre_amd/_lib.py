@@ -15,7 +15,7 @@ class TensorDesc(C.Structure):
     _fields_ = [("param", C.c_void_p), ("state0", C.c_void_p), ("state1", C.c_void_p), ("state2", C.c_void_p),
                 ("proj", C.c_void_p), ("numel", C.c_int64), ("rows", C.c_int32), ("cols", C.c_int32),
                 ("hyper", C.c_int32), ("rank", C.c_int32), ("basis", C.c_void_p), ("basis_scale", C.c_float),
-                ("reserved", C.c_int32), ("proj_split", C.c_void_p)]
+                ("split_kind", C.c_int32), ("proj_split", C.c_void_p), ("split_scale", C.c_float), ("reserved", C.c_int32)]
 
 
 class Hyper(C.Structure):
@@ -59,6 +59,8 @@ SIGNATURES = {
     "nsgp_split_projector_bytes": (C.c_size_t, [C.c_int]),
     "nsgp_split_projector": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
     "nsgp_plan_uses_split_mfma": (C.c_int, [C.c_void_p]),
+    "nsgp_split_projector_f16_bytes": (C.c_size_t, [C.c_int]),
+    "nsgp_split_projector_f16": (C.c_int, [C.c_void_p, C.c_int, C.c_float, C.c_void_p, C.c_void_p]),
     "repre_sim_workspace_bytes": (C.c_size_t, [C.c_int, C.c_int]),
     "repre_sim_counts": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t,
                                    C.c_void_p]),

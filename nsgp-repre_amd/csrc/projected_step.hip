@@ -21,6 +21,7 @@
 #include "common.hpp"
 #include "gemm_core.hpp"
 #include "gemm_bf16x3.hpp"
+#include "gemm_f16x2.hpp"
 
 namespace nsgp {
 
@@ -50,7 +51,9 @@ struct LayerDev {
     float* slabs;
     int rank, rpad, nsplit, kchunk;
     float basis_scale;
-    const __bf16* proj3;   // three-term bf16 split of proj^T (gemm_bf16x3.hpp), or null
+    const void* split;     // split copy of proj^T: kind 1 = three bf16 terms (gemm_bf16x3.hpp), 2 = two pre-scaled fp16 terms (gemm_f16x2.hpp)
+    int split_kind;
+    float split_scale;     // kind 2: the power of two the projector was multiplied by before the split
 };
 
 struct TileDev {
@@ -107,7 +110,7 @@ __device__ __forceinline__ void adam_elem(float& p, float& g, float& m, float& v
 template <int OPT>
 __global__ __launch_bounds__(256) void nsgp_update_kernel(const ChunkDev* __restrict__ chunks,
                                                           const TensorDev* __restrict__ tensors,
-                                                          const DynBlock* __restrict__ dyn) {
+                                                          const DynBlock* __restrict__ dyn, unsigned* __restrict__ amax) {
     const ChunkDev c = chunks[blockIdx.x];
     const TensorDev T = tensors[c.tensor];
     const nsgp_hyper_t h = dyn->hyper[T.hyper];
@@ -119,6 +122,9 @@ __global__ __launch_bounds__(256) void nsgp_update_kernel(const ChunkDev* __rest
     // the mutated gradient is the GEMM's A operand unless a non-Nesterov momentum buffer is
     bool wg = h.write_grad != 0;
     if (OPT == NSGP_OPT_SGD && proj && !(h.momentum != 0.0f && !h.nesterov)) wg = true;
+    // largest magnitude of what the projection will read as its A operand (fp16 split path: per-tensor scale)
+    const bool a_is_buf = (OPT == NSGP_OPT_SGD) && h.momentum != 0.0f && !h.nesterov;
+    float am = 0.0f;
     long i = c.start + (long)threadIdx.x * 4;
     if (vec) {
         for (; i + 3 < end; i += 256 * 4) {
@@ -132,7 +138,10 @@ __global__ __launch_bounds__(256) void nsgp_update_kernel(const ChunkDev* __rest
                     bv[0] = b4.x; bv[1] = b4.y; bv[2] = b4.z; bv[3] = b4.w;
                 }
 #pragma unroll
-                for (int e = 0; e < 4; ++e) sgd_elem(pv[e], gv[e], bv[e], h, proj);
+                for (int e = 0; e < 4; ++e) {
+                    sgd_elem(pv[e], gv[e], bv[e], h, proj);
+                    am = fmaxf(am, fabsf(a_is_buf ? bv[e] : gv[e]));
+                }
                 if (h.momentum != 0.0f) *reinterpret_cast<float4*>(T.s0 + i) = make_float4(bv[0], bv[1], bv[2], bv[3]);
                 if (wg && (h.weight_decay != 0.0f || (h.momentum != 0.0f && h.nesterov)))
                     *reinterpret_cast<float4*>(gp + i) = make_float4(gv[0], gv[1], gv[2], gv[3]);
@@ -147,7 +156,10 @@ __global__ __launch_bounds__(256) void nsgp_update_kernel(const ChunkDev* __rest
                     xv[0] = x4.x; xv[1] = x4.y; xv[2] = x4.z; xv[3] = x4.w;
                 }
 #pragma unroll
-                for (int e = 0; e < 4; ++e) adam_elem(pv[e], gv[e], mv[e], vv[e], xv[e], uv[e], h, proj);
+                for (int e = 0; e < 4; ++e) {
+                    adam_elem(pv[e], gv[e], mv[e], vv[e], xv[e], uv[e], h, proj);
+                    am = fmaxf(am, fabsf(uv[e]));
+                }
                 *reinterpret_cast<float4*>(T.s0 + i) = make_float4(mv[0], mv[1], mv[2], mv[3]);
                 *reinterpret_cast<float4*>(T.s1 + i) = make_float4(vv[0], vv[1], vv[2], vv[3]);
                 if (h.amsgrad) *reinterpret_cast<float4*>(T.s2 + i) = make_float4(xv[0], xv[1], xv[2], xv[3]);
@@ -159,7 +171,6 @@ __global__ __launch_bounds__(256) void nsgp_update_kernel(const ChunkDev* __rest
         // scalar tail of a tensor whose numel is not a multiple of 4
         const long tail0 = end - ((end - c.start) & 3);
         i = tail0 + threadIdx.x;
-        if (i >= end) return;
     } else {
         i = c.start + threadIdx.x;
     }
@@ -169,17 +180,23 @@ __global__ __launch_bounds__(256) void nsgp_update_kernel(const ChunkDev* __rest
         if (OPT == NSGP_OPT_SGD) {
             float bv = (h.momentum != 0.0f) ? T.s0[i] : 0.0f;
             sgd_elem(pv, gv, bv, h, proj);
+            am = fmaxf(am, fabsf(a_is_buf ? bv : gv));
             if (h.momentum != 0.0f) T.s0[i] = bv;
             if (wg && (h.weight_decay != 0.0f || (h.momentum != 0.0f && h.nesterov))) gp[i] = gv;
             if (!proj) T.p[i] = pv;
         } else {
             float mv = T.s0[i], vv = T.s1[i], xv = h.amsgrad ? T.s2[i] : 0.0f, uv;
             adam_elem(pv, gv, mv, vv, xv, uv, h, proj);
+            am = fmaxf(am, fabsf(uv));
             T.s0[i] = mv; T.s1[i] = vv;
             if (h.amsgrad) T.s2[i] = xv;
             if (wg && h.weight_decay != 0.0f) gp[i] = gv;
             if (proj) T.u[i] = uv; else T.p[i] = pv;
         }
+    }
+    if (amax && proj) {     // max is order-independent: the atomic keeps the step deterministic
+        for (int off = 32; off > 0; off >>= 1) am = fmaxf(am, __shfl_xor(am, off, 64));
+        if ((threadIdx.x & 63) == 0) atomicMax(amax + c.tensor, __float_as_uint(am));
     }
 }
 
@@ -205,10 +222,10 @@ __device__ __forceinline__ void store_tile(float* __restrict__ C, long ldc, int 
         }
 }
 
-template <int OPT, bool FAST, bool X3 = false>
+template <int OPT, bool FAST, int SPLIT = 0>
 __global__ __launch_bounds__(256, 2) void nsgp_project_kernel(const TileDev* __restrict__ tiles,
                                                               const LayerDev* __restrict__ layers,
-                                                              const DynBlock* __restrict__ dyn) {
+                                                              const DynBlock* __restrict__ dyn, const unsigned* __restrict__ amax = nullptr) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const TileDev t = tiles[blockIdx.x];
     const LayerDev L = layers[t.layer];
@@ -228,8 +245,12 @@ __global__ __launch_bounds__(256, 2) void nsgp_project_kernel(const TileDev* __r
     zero_acc(acc);
     // the grad pointer is only known at step time: a misaligned one (e.g. a view into a flat
     // bucket) takes the guarded scalar loader for the A operand only
-    if (X3 && ((uintptr_t)A & 15u) == 0)          // six bf16 MFMAs per fp32-equivalent product (gemm_bf16x3.hpp)
-        gemm_tile_bf16x3(A, L.cols, L.proj3, L.cols, t.m0, t.n0, smem, acc);
+    if (SPLIT == 2 && ((uintptr_t)A & 15u) == 0) {  // three fp16 MFMAs per fp32-equivalent product (gemm_f16x2.hpp)
+        const float sa = f2_scale_from_amax_bits(amax[L.tensor]);
+        gemm_tile_f16x2(A, L.cols, static_cast<const _Float16*>(L.split), L.cols, t.m0, t.n0, sa, smem, acc);
+        scale = scale * (1.0f / sa) * (1.0f / L.split_scale);     // both powers of two: exact
+    } else if (SPLIT == 1 && ((uintptr_t)A & 15u) == 0)          // six bf16 MFMAs per fp32-equivalent product (gemm_bf16x3.hpp)
+        gemm_tile_bf16x3(A, L.cols, static_cast<const __bf16*>(L.split), L.cols, t.m0, t.n0, smem, acc);
     else if (!FAST || ((uintptr_t)A & 15u) == 0)
         gemm_tile<FAST, FAST, false>(A, L.cols, L.proj, L.cols, L.rows, L.cols, L.cols, t.m0, t.n0, smem, acc);
     else
@@ -390,7 +411,8 @@ struct nsgp_plan {
     int n_layers = 0;
     int n_chunks = 0;
     int n_tiles_fast = 0, n_tiles_generic = 0;
-    bool use_x3 = false;        // dense fast tiles run the three-term bf16 split kernel
+    int split_kind = 0;         // dense fast tiles: 0 fp32 MFMA, 1 three-term bf16 split, 2 two-term fp16 split
+    unsigned* d_amax = nullptr; // [NSLOT][n_tensors] largest |A| per tensor, written by the elementwise launch (kind 2)
     double gemm_flops = 0, bytes = 0;
     TensorDev* d_tensors = nullptr;
     LayerDev* d_layers = nullptr;
@@ -471,7 +493,8 @@ extern "C" int nsgp_plan_create(nsgp_plan_t** out, const nsgp_tensor_t* tensors,
     std::vector<LayerDev> ld;
     std::vector<ChunkDev> cd;
     std::vector<char> layer_fast;
-    bool all_split = true;     // every fast dense layer carries the bf16 split of its projector
+    bool all_split = true;     // every fast dense layer carries a split copy of its projector, all of the same kind
+    int split_kind = 0;
     double flops = 0, bytes = 0, lr_flops = 0;
     int n_lowrank = 0;
     const int lr_kchunk = lr_pick_kchunk(tensors, n);
@@ -492,7 +515,7 @@ extern "C" int nsgp_plan_create(nsgp_plan_t** out, const nsgp_tensor_t* tensors,
                 ws_off += ((size_t)t.numel * 4 + 255) & ~(size_t)255;
             }
             LayerDev L{t.param, t.state0, d.u, t.proj, i, t.rows, t.cols, t.hyper, nullptr, nullptr, nullptr, 0, 0, 0, 0, 1.0f,
-                       static_cast<const __bf16*>(t.proj_split)};
+                       t.proj_split, t.split_kind, t.split_scale};
             if (tensor_lowrank(t)) {
                 L.basis = t.basis;
                 L.rank = t.rank;
@@ -509,7 +532,12 @@ extern "C" int nsgp_plan_create(nsgp_plan_t** out, const nsgp_tensor_t* tensors,
             }
             ld.push_back(L);
             layer_fast.push_back(tensor_fast(t) && aligned16(t.param) && aligned16(t.state0) ? 1 : 0);
-            if (layer_fast.back() && !tensor_lowrank(t) && !(t.proj_split && aligned16(t.proj_split))) all_split = false;
+            if (layer_fast.back() && !tensor_lowrank(t)) {
+                const bool ok = t.proj_split && aligned16(t.proj_split) && (t.split_kind == 1 || (t.split_kind == 2 && t.split_scale > 0.0f));
+                if (!ok) all_split = false;
+                else if (split_kind == 0) split_kind = t.split_kind;
+                else if (split_kind != t.split_kind) all_split = false;
+            }
             flops += 2.0 * t.rows * (double)t.cols * t.cols;
             bytes += 4.0 * (double)t.cols * t.cols;
         }
@@ -584,7 +612,7 @@ extern "C" int nsgp_plan_create(nsgp_plan_t** out, const nsgp_tensor_t* tensors,
     P->n_layers = (int)ld.size();
     P->n_chunks = (int)cd.size();
     P->n_tiles_fast = (int)fast_tiles.size();
-    P->use_x3 = all_split && !fast_tiles.empty();
+    P->split_kind = (all_split && !fast_tiles.empty()) ? split_kind : 0;
     P->n_tiles_generic = (int)gen_tiles.size();
     P->gemm_flops = flops;
     P->bytes = bytes;
@@ -628,6 +656,7 @@ extern "C" int nsgp_plan_create(nsgp_plan_t** out, const nsgp_tensor_t* tensors,
     } while (0)
     PLAN_HIP(hipMalloc(&P->d_tensors, sizeof(TensorDev) * td.size()));
     PLAN_HIP(hipMemcpy(P->d_tensors, td.data(), sizeof(TensorDev) * td.size(), hipMemcpyHostToDevice));
+    if (P->split_kind == 2) PLAN_HIP(hipMalloc(&P->d_amax, sizeof(unsigned) * NSLOT * (size_t)n));
     PLAN_HIP(hipMalloc(&P->d_chunks, sizeof(ChunkDev) * cd.size()));
     PLAN_HIP(hipMemcpy(P->d_chunks, cd.data(), sizeof(ChunkDev) * cd.size(), hipMemcpyHostToDevice));
     if (!lr_chunks.empty()) {
@@ -651,7 +680,8 @@ extern "C" int nsgp_plan_create(nsgp_plan_t** out, const nsgp_tensor_t* tensors,
         (rc = enable_big_lds(nsgp_lowrank_p2_kernel<NSGP_OPT_SGD>)) || (rc = enable_big_lds(nsgp_lowrank_p2_kernel<NSGP_OPT_ADAM>)) ||
         (rc = enable_big_lds(nsgp_project_kernel<NSGP_OPT_SGD, true>)) || (rc = enable_big_lds(nsgp_project_kernel<NSGP_OPT_SGD, false>)) ||
         (rc = enable_big_lds(nsgp_project_kernel<NSGP_OPT_ADAM, true>)) || (rc = enable_big_lds(nsgp_project_kernel<NSGP_OPT_ADAM, false>)) ||
-        (rc = enable_big_lds(nsgp_project_kernel<NSGP_OPT_SGD, true, true>)) || (rc = enable_big_lds(nsgp_project_kernel<NSGP_OPT_ADAM, true, true>))) {
+        (rc = enable_big_lds(nsgp_project_kernel<NSGP_OPT_SGD, true, 1>)) || (rc = enable_big_lds(nsgp_project_kernel<NSGP_OPT_ADAM, true, 1>)) ||
+        (rc = enable_big_lds(nsgp_project_kernel<NSGP_OPT_SGD, true, 2>)) || (rc = enable_big_lds(nsgp_project_kernel<NSGP_OPT_ADAM, true, 2>))) {
         nsgp_plan_destroy(P);
         return rc;
     }
@@ -667,6 +697,7 @@ extern "C" int nsgp_plan_destroy(nsgp_plan_t* P) {
         if (P->d_dyn[s]) (void)hipFree(P->d_dyn[s]);
     }
     for (hipEvent_t e : P->prof_ev) (void)hipEventDestroy(e);
+    if (P->d_amax) (void)hipFree(P->d_amax);
     if (P->d_tensors) (void)hipFree(P->d_tensors);
     if (P->d_layers) (void)hipFree(P->d_layers);
     if (P->d_tiles) (void)hipFree(P->d_tiles);
@@ -694,7 +725,18 @@ extern "C" int nsgp_plan_lowrank_stats(const nsgp_plan_t* P, int* n_lowrank, dou
     return NSGP_OK;
 }
 
-extern "C" int nsgp_plan_uses_split_mfma(const nsgp_plan_t* P) { return (P && P->use_x3) ? 1 : 0; }
+extern "C" int nsgp_plan_uses_split_mfma(const nsgp_plan_t* P) { return P ? P->split_kind : 0; }
+
+extern "C" size_t nsgp_split_projector_f16_bytes(int D) { return D > 0 ? (size_t)D * D * 4 : 0; }
+
+extern "C" int nsgp_split_projector_f16(const float* proj, int D, float scale, void* out, void* stream_) {
+    if (!proj || !out || D <= 0 || D % 8 != 0 || !(scale > 0.0f)) return fail(NSGP_ERR_INVALID, "nsgp_split_projector_f16: bad argument");
+    if (!aligned16(out)) return fail(NSGP_ERR_INVALID, "nsgp_split_projector_f16: output must be 16-byte aligned");
+    hipLaunchKernelGGL(nsgp_split_transpose_f16x2_kernel, dim3((D + 31) / 32, (D + 31) / 32), dim3(256), 0, static_cast<hipStream_t>(stream_),
+                       proj, D, D, scale, static_cast<_Float16*>(out));
+    NSGP_LAUNCH_CHECK();
+    return NSGP_OK;
+}
 
 extern "C" size_t nsgp_split_projector_bytes(int D) { return D > 0 ? (size_t)D * D * 6 : 0; }
 
@@ -727,18 +769,25 @@ extern "C" int nsgp_plan_step(nsgp_plan_t* P, float* const* grads, const nsgp_hy
     const bool prof = P->prof_n < P->prof_cap;
     if (prof) NSGP_HIP(hipEventRecord(P->prof_ev[3 * P->prof_n + 0], stream));
 
+    unsigned* amax = P->d_amax ? P->d_amax + (size_t)s * P->n_tensors : nullptr;
+    if (amax) NSGP_HIP(hipMemsetAsync(amax, 0, sizeof(unsigned) * (size_t)P->n_tensors, stream));
     if (P->optimizer == NSGP_OPT_SGD)
-        hipLaunchKernelGGL(nsgp_update_kernel<NSGP_OPT_SGD>, dim3(P->n_chunks), dim3(256), 0, stream, P->d_chunks, P->d_tensors, d);
+        hipLaunchKernelGGL(nsgp_update_kernel<NSGP_OPT_SGD>, dim3(P->n_chunks), dim3(256), 0, stream, P->d_chunks, P->d_tensors, d, amax);
     else
-        hipLaunchKernelGGL(nsgp_update_kernel<NSGP_OPT_ADAM>, dim3(P->n_chunks), dim3(256), 0, stream, P->d_chunks, P->d_tensors, d);
+        hipLaunchKernelGGL(nsgp_update_kernel<NSGP_OPT_ADAM>, dim3(P->n_chunks), dim3(256), 0, stream, P->d_chunks, P->d_tensors, d, amax);
     NSGP_LAUNCH_CHECK();
     if (prof) NSGP_HIP(hipEventRecord(P->prof_ev[3 * P->prof_n + 1], stream));
     if (P->n_tiles_fast > 0) {
-        if (P->use_x3) {
+        if (P->split_kind == 2) {
             if (P->optimizer == NSGP_OPT_SGD)
-                hipLaunchKernelGGL((nsgp_project_kernel<NSGP_OPT_SGD, true, true>), dim3(P->n_tiles_fast), dim3(THREADS), X3_SMEM_BYTES, stream, P->d_tiles, P->d_layers, d);
+                hipLaunchKernelGGL((nsgp_project_kernel<NSGP_OPT_SGD, true, 2>), dim3(P->n_tiles_fast), dim3(THREADS), F2_SMEM_BYTES, stream, P->d_tiles, P->d_layers, d, amax);
             else
-                hipLaunchKernelGGL((nsgp_project_kernel<NSGP_OPT_ADAM, true, true>), dim3(P->n_tiles_fast), dim3(THREADS), X3_SMEM_BYTES, stream, P->d_tiles, P->d_layers, d);
+                hipLaunchKernelGGL((nsgp_project_kernel<NSGP_OPT_ADAM, true, 2>), dim3(P->n_tiles_fast), dim3(THREADS), F2_SMEM_BYTES, stream, P->d_tiles, P->d_layers, d, amax);
+        } else if (P->split_kind == 1) {
+            if (P->optimizer == NSGP_OPT_SGD)
+                hipLaunchKernelGGL((nsgp_project_kernel<NSGP_OPT_SGD, true, 1>), dim3(P->n_tiles_fast), dim3(THREADS), X3_SMEM_BYTES, stream, P->d_tiles, P->d_layers, d, amax);
+            else
+                hipLaunchKernelGGL((nsgp_project_kernel<NSGP_OPT_ADAM, true, 1>), dim3(P->n_tiles_fast), dim3(THREADS), X3_SMEM_BYTES, stream, P->d_tiles, P->d_layers, d, amax);
         } else if (P->optimizer == NSGP_OPT_SGD)
             hipLaunchKernelGGL((nsgp_project_kernel<NSGP_OPT_SGD, true>), dim3(P->n_tiles_fast), dim3(THREADS), SMEM_BYTES, stream, P->d_tiles, P->d_layers, d);
         else

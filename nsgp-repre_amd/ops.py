@@ -52,6 +52,25 @@ def split_projector(P: torch.Tensor) -> torch.Tensor:
     return out
 
 
+def split_projector_f16(P: torch.Tensor):
+    """Two-term fp16 split of ``scale * P^T`` (layout [n][k/8][term][8], 4 bytes per element of P) and the power-of-two
+    ``scale`` that puts the largest |entry| of P into [2^13, 2^14) -- fp16 overflows at 65504.  One launch per projector per
+    task (plus one ``abs().max()`` to find the scale)."""
+    import math
+    lib = _lib.load_library()
+    D = P.shape[0]
+    if P.shape != (D, D):
+        raise ValueError("projector must be square")
+    m = float(P.abs().max().item())
+    if not math.isfinite(m):
+        raise ValueError("projector has non-finite entries")
+    scale = 1.0 if m == 0.0 else 2.0 ** (14 - math.frexp(m)[1])       # m = f * 2^e, f in [0.5, 1)  ->  m * scale in [2^13, 2^14)
+    scale = min(max(scale, 2.0 ** -100), 2.0 ** 100)
+    out = torch.empty(lib.nsgp_split_projector_f16_bytes(D) // 2, dtype=torch.float16, device=P.device)
+    _lib.check(lib.nsgp_split_projector_f16(_dev(P, "P"), D, scale, C.c_void_p(out.data_ptr()), _stream()), "nsgp_split_projector_f16")
+    return out, scale
+
+
 def build_projector(V: torch.Tensor, first_col: int, normalise: bool, out: torch.Tensor = None,
                     return_norm: bool = False):
     """``P = V[:, first_col:] @ V[:, first_col:].T`` (``/ ||P||_F`` if normalise) --

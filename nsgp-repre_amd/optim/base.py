@@ -25,8 +25,9 @@ from .threshold import elbow_index
 
 logger = logging.getLogger("nsgp_repre_amd")
 
-#: default of ``optimizer.split_mfma`` (see NSCLOptimizerBase.__init__)
-SPLIT_MFMA_DEFAULT = True
+#: default of ``optimizer.split_mfma`` (see NSCLOptimizerBase.__init__): False | "bf16x3" | "f16x2" (True = "f16x2")
+SPLIT_MFMA_DEFAULT = "f16x2"
+_SPLIT_KINDS = {False: 0, None: 0, "f32": 0, "bf16x3": 1, "f16x2": 2, True: 2}
 
 
 class NSCLOptimizerBase(Optimizer):
@@ -46,10 +47,11 @@ class NSCLOptimizerBase(Optimizer):
         self.low_rank = False
         #: with low_rank: orthonormalise the eigenbasis (one Newton-Schulz step) before building P from it
         self.polish_basis = True
-        #: dense projection on the bf16 matrix cores: every fp32 operand split into three bf16 terms, six MFMAs per
-        #: fp32-equivalent product with fp32 accumulation (csrc/gemm_bf16x3.hpp).  Same error against fp64 as the fp32
-        #: MFMA path, ~1.35x its rate; costs 6 extra bytes per projector element for the split copy (made once per
-        #: projector, redone if the projector tensor is replaced or modified in place).  False = fp32 MFMA.
+        #: dense projection on the low-precision matrix cores with fp32 accumulation and fp32-level error:
+        #: "f16x2" (default) -- two fp16 terms per operand, three MFMAs per fp32-equivalent product, one power-of-two scale
+        #: per operand matrix (csrc/gemm_f16x2.hpp; 4 extra bytes per projector element); "bf16x3" -- three bf16 terms, six
+        #: MFMAs, no scales (csrc/gemm_bf16x3.hpp; 6 extra bytes).  The split copy of a projector is made once and redone
+        #: if the projector tensor is replaced or modified in place.  False = fp32 MFMA.
         self.split_mfma = SPLIT_MFMA_DEFAULT
         self._splits = {}
         self._basis = {}
@@ -199,7 +201,7 @@ class NSCLOptimizerBase(Optimizer):
         lib = _lib.load_library()
         self._destroy_plans()
         live = {(P.data_ptr(), P._version) for P in self.transforms.values() if isinstance(P, torch.Tensor)}
-        self._splits = {k: v for k, v in self._splits.items() if k in live}      # drop splits of replaced projectors
+        self._splits = {k: v for k, v in self._splits.items() if k[:2] in live}  # drop splits of replaced projectors
         groups = sorted({gi for gi, *_ in entries})
         for lo in range(0, len(groups), _lib.NSGP_MAX_HYPER):
             gset = groups[lo:lo + _lib.NSGP_MAX_HYPER]
@@ -226,8 +228,10 @@ class NSCLOptimizerBase(Optimizer):
                                            f"{tuple(P.shape)} {P.dtype} {P.device}")
                     d.proj = P.data_ptr()
                     d.rows, d.cols = rows, cols
-                    if self.split_mfma and rows % 128 == 0 and cols % 128 == 0:
-                        d.proj_split = self._split_of(P).data_ptr()
+                    kind = _SPLIT_KINDS[self.split_mfma]
+                    if kind and rows % 128 == 0 and cols % 128 == 0:
+                        sp, sc = self._split_of(P, kind)
+                        d.proj_split, d.split_kind, d.split_scale = sp.data_ptr(), kind, sc
                     b = self._basis.get(n)
                     if self.low_rank and b is not None and b["P_ptr"] == P.data_ptr() and b["V"].is_contiguous():
                         d.basis = b["V"].data_ptr()          # only for projectors this optimizer built itself
@@ -244,19 +248,19 @@ class NSCLOptimizerBase(Optimizer):
             self._plans.append(dict(handle=handle, entries=sub, groups=gset,
                                     grads=(C.c_void_p * len(sub))(), hyper=(_lib.Hyper * len(gset))()))
 
-    def _split_of(self, P: torch.Tensor) -> torch.Tensor:
-        """The three-term bf16 split of ``P^T`` (``nsgp_split_projector``), cached per (storage, version)."""
-        from .. import ops
-        k = (P.data_ptr(), P._version)
+    def _split_of(self, P: torch.Tensor, kind: int):
+        """(split copy of ``P^T``, scale) of the given kind, cached per (storage, version, kind)."""
+        k = (P.data_ptr(), P._version, kind)
         hit = self._splits.get(k)
         if hit is None:
-            hit = self._splits[k] = ops.split_projector(P)
+            hit = self._splits[k] = (ops.split_projector(P), 1.0) if kind == 1 else ops.split_projector_f16(P)
         return hit
 
-    def uses_split_mfma(self) -> bool:
-        """True if every current plan runs its dense projection launch on the three-term bf16 split."""
+    def uses_split_mfma(self):
+        """The split kind every current plan runs its dense projection launch on: False, "bf16x3" or "f16x2"."""
         lib = _lib.load_library()
-        return bool(self._plans) and all(lib.nsgp_plan_uses_split_mfma(p["handle"]) == 1 for p in self._plans)
+        kinds = {lib.nsgp_plan_uses_split_mfma(p["handle"]) for p in self._plans}
+        return {1: "bf16x3", 2: "f16x2"}.get(kinds.pop(), False) if len(kinds) == 1 else False
 
     def plan_stats(self):
         """(gemm_flops, algorithmic_bytes, n_tiles, n_projected) summed over the current plans."""
@@ -319,7 +323,7 @@ class NSCLOptimizerBase(Optimizer):
                 loss = closure()
         lib = _lib.load_library()
         transforms, state = self.transforms, self.state
-        key = [bool(self.low_rank), bool(self.split_mfma)]
+        key = [bool(self.low_rank), _SPLIT_KINDS[self.split_mfma]]
         for gi, group in enumerate(self.param_groups):
             svd = group["svd"]
             for n, p in zip(group["names"], group["params"]):

@@ -276,7 +276,7 @@ def test_full_size_step_properties(N, dev):
     assert _rel(once, ref) <= 1e-5
 
 
-@pytest.mark.parametrize("split", [False, True])
+@pytest.mark.parametrize("split", [False, "bf16x3", "f16x2"])
 def test_full_r50_table_one_step_vs_torch_gpu(N, dev, split):
     """The complete 50-layer R-50-FPN table (BASELINE configs[1]) in one plan: every
     projected parameter must equal p - lr*(buf @ P) computed layer by layer with torch on the
@@ -475,35 +475,41 @@ def test_split_projector_terms_sum_to_the_projector(N, dev):
         assert (terms[1].abs() <= 2.0 ** -8 * terms[0].abs() + 1e-38).all()                    # each term is a residual of the last
 
 
-@pytest.mark.parametrize("kind", ["sgd", "adamw"])
-def test_split_mfma_steps_vs_oracle(N, dev, kind):
-    """The bf16x3 projection path against the CPU oracle under the same 1e-5 gate as the fp32 path: aligned layers run
-    the split kernel, a ragged layer in the same plan stays on the generic fp32 tiles, a plain tensor is untouched."""
+@pytest.mark.parametrize("split", ["bf16x3", "f16x2"])
+@pytest.mark.parametrize("kind", ["sgd", "sgd_nomomentum", "sgd_nesterov", "adamw"])
+def test_split_mfma_steps_vs_oracle(N, dev, kind, split):
+    """Both split projection paths against the CPU oracle under the same 1e-5 gate as the fp32 path: aligned layers run
+    the split kernel, a ragged layer in the same plan stays on the generic fp32 tiles, a plain tensor is untouched.  The SGD
+    flavours differ in WHICH array is the projection's A operand (momentum buffer / mutated gradient), i.e. in what the
+    per-tensor fp16 scale is measured on."""
     shapes = {"backbone.a.weight": (128, 256), "backbone.b.weight": (256, 128, 3, 3), "neck.c.weight": (256, 256, 3, 3),
               "backbone.ragged.weight": (100, 36, 3, 3), "rpn_head.x.weight": (64, 40)}
     names = list(shapes)
     tr = _proj_for(shapes, names[:4])
-    hp = dict(lr=0.02, momentum=0.9, weight_decay=1e-4) if kind == "sgd" else dict(lr=1e-3, weight_decay=0.05)
-    opt, params, cpu, init = _run_both(N, dev, [(names, hp)], shapes, tr, steps=3, kind=kind, split_mfma=True)
-    assert opt.uses_split_mfma()
-    _check(params, cpu, init, "split-" + kind)
+    hp = {"sgd": dict(lr=0.02, momentum=0.9, weight_decay=1e-4), "sgd_nomomentum": dict(lr=0.02, momentum=0.0, weight_decay=1e-4),
+          "sgd_nesterov": dict(lr=0.02, momentum=0.9, weight_decay=1e-4, nesterov=True), "adamw": dict(lr=1e-3, weight_decay=0.05)}[kind]
+    okind = "adamw" if kind == "adamw" else "sgd"
+    opt, params, cpu, init = _run_both(N, dev, [(names, hp)], shapes, tr, steps=3, kind=okind, split_mfma=split)
+    assert opt.uses_split_mfma() == split
+    _check(params, cpu, init, f"{split}-{kind}")
     # the same run on the fp32 MFMA path lands within the same gate of the split run
-    opt2, params2, cpu2, init2 = _run_both(N, dev, [(names, hp)], shapes, tr, steps=3, kind=kind, split_mfma=False)
+    opt2, params2, cpu2, init2 = _run_both(N, dev, [(names, hp)], shapes, tr, steps=3, kind=okind, split_mfma=False)
     assert not opt2.uses_split_mfma()
     for n in shapes:
         upd = (cpu[n] - init[n]).abs().max().item()
         assert (params[n] - params2[n]).abs().max().item() <= REL * upd + 4 * 2.0 ** -23 * cpu[n].abs().max().item(), n
 
 
-def test_split_mfma_with_misaligned_gradients_and_projector_edits(N, dev):
+@pytest.mark.parametrize("split", ["bf16x3", "f16x2"])
+def test_split_mfma_with_misaligned_gradients_and_projector_edits(N, dev, split):
     """(i) gradient views at odd offsets: the split kernel's tile falls back to the guarded fp32 loader for that operand;
     (ii) an in-place edit of a projector invalidates its cached split (tensor version in the plan key)."""
     shapes = {"backbone.a.weight": (128, 256), "neck.c.weight": (256, 128, 3, 3)}
     names = list(shapes)
     tr = _proj_for(shapes, names)
     hp = dict(lr=0.05, momentum=0.0, weight_decay=0.0)
-    opt, params, cpu, init = _run_both(N, dev, [(names, hp)], shapes, tr, steps=2, grad_views=True, split_mfma=True)
-    assert opt.uses_split_mfma()
+    opt, params, cpu, init = _run_both(N, dev, [(names, hp)], shapes, tr, steps=2, grad_views=True, split_mfma=split)
+    assert opt.uses_split_mfma() == split
     _check(params, cpu, init, "split-misaligned")
     n = names[0]
     before = params[n].detach().clone()
@@ -514,6 +520,35 @@ def test_split_mfma_with_misaligned_gradients_and_projector_edits(N, dev):
     opt.step()
     want = before.cpu() + O.project_update(-(0.05 * g), 0.5 * tr[n])
     assert _rel(params[n].detach() - before, want - before.cpu()) <= REL
+
+
+def test_f16x2_split_survives_a_wide_dynamic_range(N, dev):
+    """fp16 has a 5-bit exponent: the two-term path scales each operand matrix by one power of two.  Updates 1e+4 and 1e-6
+    times the usual size, rows of the update 1e-6 times smaller than the rest, a projector with tiny entries and an all-zero
+    gradient must all stay inside the gate (relative to the tensor's largest update) -- and no inf / nan may appear."""
+    from nsgp_repre_amd import ops
+    D, rows = 256, 128
+    g = torch.Generator().manual_seed(21)
+    sv, V = O.eigens(torch.from_numpy(I.covariance_like(D, 33, rows_mult=2)))
+    P = O.build_projector(V, O.adaptive_threshold(sv, 0.0), True)
+    for gscale, row_scale, pscale in ((1e4, 1.0, 1.0), (1e-6, 1.0, 1.0), (1.0, 1e-6, 1.0), (1.0, 1.0, 1e-7), (0.0, 1.0, 1.0)):
+        grad = torch.randn(rows, D, generator=g) * gscale
+        grad[: rows // 2] *= row_scale
+        Pc = P * pscale
+        p = torch.nn.Parameter(torch.zeros(rows, D, device=dev))
+        opt = N.SGDNSCL([p], lr=1.0, momentum=0.0, svd=True)
+        opt.param_groups[0]["names"] = ["backbone.w.weight"]
+        opt.transforms["backbone.w.weight"] = Pc.to(dev)
+        opt.split_mfma = "f16x2"
+        p.grad = grad.clone().to(dev)
+        opt.step()
+        assert opt.uses_split_mfma() == "f16x2"
+        got = p.detach().cpu()
+        want = (-(grad.double()) @ Pc.double())
+        assert torch.isfinite(got).all()
+        assert (got.double() - want).abs().max().item() <= REL * max(want.abs().max().item(), 1e-300), (gscale, row_scale, pscale)
+    sp, sc = ops.split_projector_f16(P.to(dev))
+    assert 2.0 ** 13 <= float(P.abs().max()) * sc < 2.0 ** 14 and sp.dtype == torch.float16
 
 
 def test_param_groups_with_different_hyperparameters(N, dev):
@@ -571,7 +606,7 @@ def test_adamw_param_groups(N, dev):
 
 
 # ------------------------------------------------------------------ the other BASELINE configs as parity cases
-@pytest.mark.parametrize("split", [False, True])
+@pytest.mark.parametrize("split", [False, "bf16x3", "f16x2"])
 def test_r101_table_one_step_vs_torch_gpu(N, dev, split):
     """configs[4] (R-101-FPN): 101 projected layers, 175.9 GFLOP, one plan."""
     layers = O.resnet_fpn_projected_layers(101)
