@@ -126,6 +126,106 @@ __global__ __launch_bounds__(256, 2) void f2_kernel(const float* __restrict__ A,
         C[(long)(m0 + wm * 64 + mi * 32 + acc_row(e, lane)) * N + n0 + wn * 64 + ni * 32 + (lane & 31)] = acc[mi][ni][e] * unscale;
 }
 
+// ---- variant: k32 steps (two MFMA k16 sub-steps per barrier), full 128-B lines per row and thread pair -----------------
+constexpr int G2_OCT = BM * 8 + 32;
+constexpr int G2_PLANE = 4 * G2_OCT;             // 4 octets per step
+constexpr int G2_STAGE = 4 * G2_PLANE;           // A0 A1 B0 B1: 33,792 B
+struct G2Regs { f32x4 a[4]; h16x8 b[4]; };       // octets 2*(t&1), 2*(t&1)+1: A 16 floats, B 2 octets x 2 terms
+
+template <int NSETS>
+__global__ __launch_bounds__(256, 2) void g2_kernel(const float* __restrict__ A, const _Float16* __restrict__ Bt, float* __restrict__ C,
+                                                    int M, int N, int K, float a_scale, float unscale) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    _Float16* smem = reinterpret_cast<_Float16*>(sm);
+    const int t = threadIdx.x, wave = t >> 6, lane = t & 63, wm = wave >> 1, wn = wave & 1;
+    const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+    f32x16 acc[2][2];
+    zero_acc(acc);
+    const float* pa = A + (long)(m0 + (t >> 1)) * K + (t & 1) * 16;
+    const _Float16* pb = Bt + (long)(n0 + (t >> 1)) * K * 2 + (t & 1) * 32;
+    const int slot = (t & 1) * 2 * G2_OCT + (t >> 1) * 8;
+    const int nk = K / 32, last = nk - 1;
+    auto load = [&](long k0, G2Regs& r) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) r.a[i] = *(const gf32x4*)(pa + k0 + 4 * i);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) r.b[i] = *(const g_h16x8*)(pb + 2 * k0 + 8 * i);     // oct0 t0, oct0 t1, oct1 t0, oct1 t1
+    };
+    auto write_a = [&](_Float16* st, const G2Regs& r) {
+#pragma unroll
+        for (int o = 0; o < 2; ++o) {
+            h16x8 p0, p1;
+            f2_split(r.a[2 * o], r.a[2 * o + 1], a_scale, p0, p1);
+            *reinterpret_cast<h16x8*>(st + 0 * G2_PLANE + slot + o * G2_OCT) = p0;
+            *reinterpret_cast<h16x8*>(st + 1 * G2_PLANE + slot + o * G2_OCT) = p1;
+        }
+    };
+    auto write_b = [&](_Float16* st, const G2Regs& r) {
+#pragma unroll
+        for (int o = 0; o < 2; ++o) {
+            *reinterpret_cast<h16x8*>(st + 2 * G2_PLANE + slot + o * G2_OCT) = r.b[2 * o];
+            *reinterpret_cast<h16x8*>(st + 3 * G2_PLANE + slot + o * G2_OCT) = r.b[2 * o + 1];
+        }
+    };
+    G2Regs regs[NSETS];
+#pragma unroll
+    for (int i = 0; i < NSETS; ++i) load((long)min(i, last) * 32, regs[i]);
+    write_a(smem, regs[0]); write_b(smem, regs[0]);
+    load((long)min(NSETS, last) * 32, regs[0]);
+    __syncthreads();
+    auto step = [&](int kt, auto rb, auto s) {
+        constexpr int RB = decltype(rb)::value, S = decltype(s)::value;
+        const _Float16* cur = smem + RB * G2_STAGE;
+        _Float16* nxt = smem + (1 - RB) * G2_STAGE;
+        const int r = lane & 31, h = lane >> 5;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            h16x8 fa[2][2], fb[2][2];
+#pragma unroll
+            for (int p = 0; p < 2; ++p)
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    fa[i][p] = *reinterpret_cast<const h16x8*>(cur + p * G2_PLANE + (2 * ks + h) * G2_OCT + (wm * 64 + i * 32 + r) * 8);
+                    fb[i][p] = *reinterpret_cast<const h16x8*>(cur + (2 + p) * G2_PLANE + (2 * ks + h) * G2_OCT + (wn * 64 + i * 32 + r) * 8);
+                }
+#pragma unroll
+            for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+                for (int ni = 0; ni < 2; ++ni) acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[mi][1], fb[ni][0], acc[mi][ni], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(SCHED_PIN_STAGING);
+            if (ks == 0) write_a(nxt, regs[S]); else write_b(nxt, regs[S]);
+#pragma unroll
+            for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+                for (int ni = 0; ni < 2; ++ni) acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[mi][0], fb[ni][1], acc[mi][ni], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(SCHED_PIN_STAGING);
+            if (ks == 1) { load((long)min(kt + 1 + NSETS, last) * 32, regs[S]); __builtin_amdgcn_sched_barrier(SCHED_PIN_VMEM_READ); }
+#pragma unroll
+            for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+                for (int ni = 0; ni < 2; ++ni) acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[mi][0], fb[ni][0], acc[mi][ni], 0, 0, 0);
+        }
+        __syncthreads();
+    };
+    int kt = 0;
+    if (NSETS == 2) {
+        for (; kt + 1 < nk; kt += 2) { step(kt, IC<0>{}, IC<1>{}); step(kt + 1, IC<1>{}, IC<0>{}); }
+        if (kt < nk) step(kt, IC<0>{}, IC<1>{});
+    } else {
+        for (; kt + 5 < nk; kt += 6) {
+            step(kt, IC<0>{}, IC<1 % NSETS>{}); step(kt + 1, IC<1>{}, IC<2 % NSETS>{}); step(kt + 2, IC<0>{}, IC<0>{});
+            step(kt + 3, IC<1>{}, IC<1 % NSETS>{}); step(kt + 4, IC<0>{}, IC<2 % NSETS>{}); step(kt + 5, IC<1>{}, IC<0>{});
+        }
+        if (kt < nk) { step(kt, IC<0>{}, IC<1 % NSETS>{}); ++kt; }
+        if (kt < nk) { step(kt, IC<1>{}, IC<2 % NSETS>{}); ++kt; }
+        if (kt < nk) { step(kt, IC<0>{}, IC<0>{}); ++kt; }
+        if (kt < nk) { step(kt, IC<1>{}, IC<1 % NSETS>{}); ++kt; }
+        if (kt < nk) { step(kt, IC<0>{}, IC<2 % NSETS>{}); ++kt; }
+    }
+    for (int mi = 0; mi < 2; ++mi) for (int ni = 0; ni < 2; ++ni) for (int e = 0; e < 16; ++e)
+        C[(long)(m0 + wm * 64 + mi * 32 + acc_row(e, lane)) * N + n0 + wn * 64 + ni * 32 + (lane & 31)] = acc[mi][ni][e] * unscale;
+}
+
 template <class F>
 static float time_it(F f) {
     hipEvent_t e0, e1; (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
@@ -160,6 +260,18 @@ int main() {
         const float t0 = time_it([&] { hipLaunchKernelGGL(f2_kernel<0>, dim3(N / BN, M / BM), dim3(256), F2_SMEM, 0, A, Bt, C, M, N, K, sa, 1.0f / (sa * sb)); });
         const float t1 = time_it([&] { hipLaunchKernelGGL(f2_kernel<1>, dim3(N / BN, M / BM), dim3(256), F2_SMEM, 0, A, Bt, C, M, N, K, sa, 1.0f / (sa * sb)); });
         printf("round %d  f16x2 tile %.3f ms = %.1f TF fp32-equivalent   (no global loads in the loop: %.1f)\n", round, t0, fl / t0 / 1e9, fl / t1 / 1e9);
+    }
+    {   // k32-step variants: same results expected (same summation order per accumulator)
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(g2_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * G2_STAGE * 2);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(g2_kernel<3>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * G2_STAGE * 2);
+        hipLaunchKernelGGL(f2_kernel<0>, dim3(N / BN, M / BM), dim3(256), F2_SMEM, 0, A, Bt, C, M, N, K, sa, 1.0f / (sa * sb));
+        std::vector<float> c0((size_t)M * N), c1((size_t)M * N);
+        (void)hipMemcpy(c0.data(), C, c0.size() * 4, hipMemcpyDeviceToHost);
+        const float g2 = time_it([&] { hipLaunchKernelGGL(g2_kernel<2>, dim3(N / BN, M / BM), dim3(256), 2 * G2_STAGE * 2, 0, A, Bt, C, M, N, K, sa, 1.0f / (sa * sb)); });
+        (void)hipMemcpy(c1.data(), C, c1.size() * 4, hipMemcpyDeviceToHost);
+        double dm = 0; for (size_t i = 0; i < c0.size(); ++i) dm = std::max(dm, (double)fabsf(c0[i] - c1[i]));
+        const float g3 = time_it([&] { hipLaunchKernelGGL(g2_kernel<3>, dim3(N / BN, M / BM), dim3(256), 2 * G2_STAGE * 2, 0, A, Bt, C, M, N, K, sa, 1.0f / (sa * sb)); });
+        printf("k32-step variant: 2 register sets %.3f ms = %.1f TF-eq | 3 sets %.3f ms = %.1f TF-eq   max|diff| vs k16 tile %.3g\n", g2, fl / g2 / 1e9, g3, fl / g3 / 1e9, dm);
     }
     hipLaunchKernelGGL(f2_kernel<0>, dim3(N / BN, M / BM), dim3(256), F2_SMEM, 0, A, Bt, C, M, N, K, sa, 1.0f / (sa * sb));
     std::vector<float> c((size_t)M * N);
