@@ -165,6 +165,11 @@ int nsgp_project(const float* a, const float* proj, float* out, int rows, int co
  * accumulate=0 is the reference's first call (assign), 1 the later ones (add).
  * ------------------------------------------------------------------------ */
 size_t nsgp_cov_workspace_bytes(int cin, int h, int w, int kh, int kw, int sh, int sw, int ph, int pw);
+/* Process-wide choice of the SYRK's matrix-core path: 0 = fp32 MFMA, 2 = two-term fp16 split (three fp16 MFMAs per
+ * fp32-equivalent product, one power-of-two scale per layer found from the batch mean; fp32-level error), 1 (default) = the
+ * split for layers large enough to repay its two extra tiny launches.  Returns the previous setting.  The workspace size
+ * covers both paths. */
+int nsgp_cov_set_split_mfma(int mode);
 int nsgp_cov_accumulate_conv2d(const float* x, int batch, int cin, int h, int w, int kh, int kw,
                                int sh, int sw, int ph, int pw, float* cov, int accumulate,
                                void* workspace, size_t workspace_bytes, void* stream);

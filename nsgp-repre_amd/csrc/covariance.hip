@@ -19,6 +19,7 @@
 
 #include "common.hpp"
 #include "gemm_core.hpp"
+#include "gemm_f16x2.hpp"
 
 namespace nsgp {
 
@@ -167,6 +168,166 @@ __global__ __launch_bounds__(256, 2) void nsgp_cov_syrk_kernel(const float* __re
     }
 }
 
+// ---- two-term fp16 split variant of the SYRK (gemm_f16x2.hpp): three fp16 MFMAs per fp32-equivalent product ---------
+// Both operands are the implicit X^T, so ONE power-of-two scale s (largest |activation| of the batch mean -> [2^13, 2^14)) serves
+// both and the reduce kernel undoes s^2 exactly.  Steps are k16 (16 output positions); thread t stages row (t>>1), positions
+// 8*(t&1) .. +7 of each operand as fp32 and splits them while writing to LDS.
+__global__ __launch_bounds__(256) void nsgp_amax_kernel(const float* __restrict__ x, long n, unsigned* __restrict__ out) {
+    float am = 0.0f;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) am = fmaxf(am, fabsf(x[i]));
+    for (int off = 32; off > 0; off >>= 1) am = fmaxf(am, __shfl_xor(am, off, 64));
+    if ((threadIdx.x & 63) == 0) atomicMax(out, __float_as_uint(am));
+}
+
+struct Patch8 {
+    long off[8];     // -1 = past the end of this K range
+    bool contig[2];  // each group of 4 positions sits in one output row of a stride-1 convolution
+};
+
+__device__ __forceinline__ Patch8 patch8(const ConvGeom& g, float inv_wo, int l, int l_end) {
+    Patch8 pc;
+    int oy = (int)((float)l * inv_wo);
+    oy -= (oy * g.Wo > l);
+    oy += ((oy + 1) * g.Wo <= l);
+    int ox = l - oy * g.Wo;
+    long row = (long)oy * g.sh * g.Wp;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        if ((e & 3) == 0) pc.contig[e >> 2] = (g.sw == 1) && (ox + 3 < g.Wo) && (l + e + 3 < l_end);
+        pc.off[e] = (l + e < l_end) ? (row + (long)ox * g.sw) : -1;
+        if (++ox >= g.Wo) { ox = 0; row += (long)g.sh * g.Wp; }
+    }
+    return pc;
+}
+
+__device__ __forceinline__ void stage8(const float* __restrict__ xm, long rowbase, const Patch8& pc, f32x4 (&r)[2]) {
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        if (rowbase >= 0 && pc.contig[h]) {
+            const f32x4_u q = *(const gf32x4_u*)(xm + rowbase + pc.off[4 * h]);
+            r[h][0] = q[0]; r[h][1] = q[1]; r[h][2] = q[2]; r[h][3] = q[3];
+        } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                r[h][e] = (rowbase >= 0 && pc.off[4 * h + e] >= 0) ? as_global(xm)[rowbase + pc.off[4 * h + e]] : 0.0f;
+        }
+    }
+}
+
+__device__ __forceinline__ long im2col_rowbase1(const ConvGeom& g, int d) {
+    if (d >= g.D) return -1;
+    const int kk = g.kh * g.kw;
+    const int c = d / kk, rem = d - c * kk, i = rem / g.kw, jj = rem - i * g.kw;
+    return ((long)c * g.Hp + i) * g.Wp + jj;
+}
+
+struct CovF2Regs {
+    f32x4 a[2], b[2];
+};
+
+__global__ __launch_bounds__(256, 2) void nsgp_cov_syrk_f16_kernel(const float* __restrict__ xm, ConvGeom g, int nk, long G,
+                                                                   const unsigned* __restrict__ amax, float* __restrict__ slabs) {
+    extern __shared__ __attribute__((aligned(16))) float smem_f[];
+    _Float16* smem = reinterpret_cast<_Float16*>(smem_f);
+    const int nb = (g.D + BM - 1) / BM;
+    const long P = gridDim.x, w = blockIdx.x;
+    const int t = threadIdx.x, wave = t >> 6, lane = t & 63, wm = wave >> 1, wn = wave & 1;
+    const float scale = f2_scale_from_amax_bits(*amax);
+    const float inv_wo = 1.0f / (float)g.Wo;
+    const int slot = (t & 1) * F2_OCT + (t >> 1) * 8;
+    long gi = sk_begin(w, G, P);
+    const long g_end = sk_begin(w + 1, G, P);
+    while (gi < g_end) {                                       // uniform across the workgroup
+        const int tile = (int)(gi / nk);
+        const int ja = (int)(gi - (long)tile * nk);
+        const int jb = (int)min((long)nk, ja + (g_end - gi));
+        int ti, tj;
+        tile_of(tile, nb, ti, tj);
+        const int m0 = ti * BM, n0 = tj * BN;
+        const int l_beg = ja * F2_BK, l_end = min(jb * F2_BK, g.L);
+        const int nsteps = jb - ja, last = nsteps - 1;
+        const long base_a = im2col_rowbase1(g, m0 + (t >> 1)), base_b = im2col_rowbase1(g, n0 + (t >> 1));
+        f32x16 acc[2][2];
+        zero_acc(acc);
+        auto load = [&](int step, CovF2Regs& r) {
+            const Patch8 pc = patch8(g, inv_wo, l_beg + step * F2_BK + (t & 1) * 8, l_end);   // shared by both operands
+            stage8(xm, base_a, pc, r.a);
+            stage8(xm, base_b, pc, r.b);
+        };
+        auto write = [&](_Float16* st, const CovF2Regs& r) {
+            h16x8 p0, p1;
+            f2_split(r.a[0], r.a[1], scale, p0, p1);
+            *reinterpret_cast<h16x8*>(st + 0 * F2_PLANE + slot) = p0;
+            *reinterpret_cast<h16x8*>(st + 1 * F2_PLANE + slot) = p1;
+            f2_split(r.b[0], r.b[1], scale, p0, p1);
+            *reinterpret_cast<h16x8*>(st + 2 * F2_PLANE + slot) = p0;
+            *reinterpret_cast<h16x8*>(st + 3 * F2_PLANE + slot) = p1;
+        };
+        CovF2Regs regs[3];
+        load(0, regs[0]);
+        load(min(1, last), regs[1]);
+        load(min(2, last), regs[2]);
+        write(smem, regs[0]);
+        load(min(3, last), regs[0]);
+        __syncthreads();
+        auto step = [&](int kt, auto rb, auto s) {
+            constexpr int RB = decltype(rb)::value, S = decltype(s)::value;
+            const _Float16* cur = smem + RB * F2_STAGE;
+            _Float16* nxt = smem + (1 - RB) * F2_STAGE;
+            const int r = lane & 31, h = lane >> 5;
+            h16x8 fa[2][2], fb[2][2];
+#pragma unroll
+            for (int p = 0; p < 2; ++p)
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    fa[i][p] = *reinterpret_cast<const h16x8*>(cur + p * F2_PLANE + h * F2_OCT + (wm * 64 + i * 32 + r) * 8);
+                    fb[i][p] = *reinterpret_cast<const h16x8*>(cur + (2 + p) * F2_PLANE + h * F2_OCT + (wn * 64 + i * 32 + r) * 8);
+                }
+#pragma unroll
+            for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+                for (int ni = 0; ni < 2; ++ni) acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[mi][1], fb[ni][0], acc[mi][ni], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(SCHED_PIN_STAGING);
+            write(nxt, regs[S]);
+#pragma unroll
+            for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+                for (int ni = 0; ni < 2; ++ni) acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[mi][0], fb[ni][1], acc[mi][ni], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(SCHED_PIN_STAGING);
+            load(min(kt + 4, last), regs[S]);
+            __builtin_amdgcn_sched_barrier(SCHED_PIN_VMEM_READ);
+#pragma unroll
+            for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+                for (int ni = 0; ni < 2; ++ni) acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[mi][0], fb[ni][0], acc[mi][ni], 0, 0, 0);
+            __syncthreads();
+        };
+        int kt = 0;
+        for (; kt + 5 < nsteps; kt += 6) {
+            step(kt, IC<0>{}, IC<1>{});
+            step(kt + 1, IC<1>{}, IC<2>{});
+            step(kt + 2, IC<0>{}, IC<0>{});
+            step(kt + 3, IC<1>{}, IC<1>{});
+            step(kt + 4, IC<0>{}, IC<2>{});
+            step(kt + 5, IC<1>{}, IC<0>{});
+        }
+        if (kt < nsteps) { step(kt, IC<0>{}, IC<1>{}); ++kt; }
+        if (kt < nsteps) { step(kt, IC<1>{}, IC<2>{}); ++kt; }
+        if (kt < nsteps) { step(kt, IC<0>{}, IC<0>{}); ++kt; }
+        if (kt < nsteps) { step(kt, IC<1>{}, IC<1>{}); ++kt; }
+        if (kt < nsteps) { step(kt, IC<0>{}, IC<2>{}); ++kt; }
+        float* out = slabs + ((long)tile + w) * (BM * BN);
+        acc_to_lds(smem_f, acc);
+        for_each_row4(smem_f, [&](int r, int col, float4 v) {
+            f32x4 q;
+            q[0] = v.x; q[1] = v.y; q[2] = v.z; q[3] = v.w;
+            *(gf32x4*)(out + r * BN + col) = q;
+        });
+        __syncthreads();
+        gi += nsteps;
+    }
+}
+
 constexpr int RED_LD = BN + 1;
 constexpr int RED_MAX_ROWS = 64;
 
@@ -174,8 +335,11 @@ constexpr int RED_MAX_ROWS = 64;
 // the tile's segments in workgroup order, writes it and its mirror.  R grows when there are few tiles -- a D=64
 // layer is ONE tile cut into 512 segments, and a single workgroup would stream all 32 MB of slabs by itself.
 __global__ __launch_bounds__(256) void nsgp_cov_reduce_kernel(const float* __restrict__ slabs, int D, int nk, long G, long P,
-                                                              int rows, float* __restrict__ cov, int accumulate) {
+                                                              int rows, float* __restrict__ cov, int accumulate,
+                                                              const unsigned* __restrict__ amax) {
     __shared__ float tile[RED_MAX_ROWS * RED_LD];
+    float unscale = 1.0f;                                       // fp16 path: the operands were multiplied by s (a power of two)
+    if (amax) { const float sc = f2_scale_from_amax_bits(*amax); unscale = (1.0f / sc) * (1.0f / sc); }
     const int nb = (D + BM - 1) / BM;
     const int t = blockIdx.x, r0 = blockIdx.y * rows;
     int ti, tj;
@@ -183,16 +347,28 @@ __global__ __launch_bounds__(256) void nsgp_cov_reduce_kernel(const float* __res
     const int m0 = ti * BM, n0 = tj * BN;
     if (m0 + r0 >= D) return;                                   // band entirely below the matrix edge
     const long w_first = sk_owner((long)t * nk, G, P), w_last = sk_owner((long)(t + 1) * nk - 1, G, P);
-    for (int idx = threadIdx.x; idx < rows * BN / 4; idx += 256) {
-        const int r = idx / (BN / 4), c4 = (idx - r * (BN / 4)) * 4;
-        const long off = (long)(r0 + r) * BN + c4;
-        f32x4 sum = *(const gf32x4*)(slabs + ((long)t + w_first) * (BM * BN) + off);
-        for (long w = w_first + 1; w <= w_last; ++w) {
-            const f32x4 v = *(const gf32x4*)(slabs + ((long)t + w) * (BM * BN) + off);
-            sum[0] += v[0]; sum[1] += v[1]; sum[2] += v[2]; sum[3] += v[3];
-        }
+    if (ti != tj || !amax) {
+        for (int idx = threadIdx.x; idx < rows * BN / 4; idx += 256) {
+            const int r = idx / (BN / 4), c4 = (idx - r * (BN / 4)) * 4;
+            const long off = (long)(r0 + r) * BN + c4;
+            f32x4 sum = *(const gf32x4*)(slabs + ((long)t + w_first) * (BM * BN) + off);
+            for (long w = w_first + 1; w <= w_last; ++w) {
+                const f32x4 v = *(const gf32x4*)(slabs + ((long)t + w) * (BM * BN) + off);
+                sum[0] += v[0]; sum[1] += v[1]; sum[2] += v[2]; sum[3] += v[3];
+            }
 #pragma unroll
-        for (int e = 0; e < 4; ++e) tile[r * RED_LD + c4 + e] = sum[e];
+            for (int e = 0; e < 4; ++e) tile[r * RED_LD + c4 + e] = sum[e] * unscale;
+        }
+    } else {
+        // Diagonal tile of the split path: (i,j) and (j,i) hold the same three products per position in a different order,
+        // so they can differ in the last bit.  Take the upper triangle for both: C stays exactly symmetric, as on the fp32 path.
+        for (int idx = threadIdx.x; idx < rows * BN; idx += 256) {
+            const int r = idx >> 7, c = idx & 127, ra = r0 + r;
+            const long off = (c >= ra) ? (long)ra * BN + c : (long)c * BN + ra;
+            float sum = as_global(slabs)[((long)t + w_first) * (BM * BN) + off];
+            for (long w = w_first + 1; w <= w_last; ++w) sum += as_global(slabs)[((long)t + w) * (BM * BN) + off];
+            tile[r * RED_LD + c] = sum * unscale;
+        }
     }
     __syncthreads();
     for (int idx = threadIdx.x; idx < rows * BN; idx += 256) {
@@ -234,10 +410,12 @@ struct CovPlan {
     long tiles, G, P;
 };
 
-static CovPlan cov_plan(int D, int L) {
+static int g_cov_split = 1;    // 0: fp32 MFMA SYRK, 1: auto (default: the fp16 split where the extra amax launch pays), 2: always the fp16 split
+
+static CovPlan cov_plan(int D, int L, int kstep) {
     const int nb = (D + BM - 1) / BM;
     CovPlan p;
-    p.nk = (L + BK - 1) / BK;
+    p.nk = (L + kstep - 1) / kstep;
     p.tiles = (long)nb * (nb + 1) / 2;
     p.G = p.tiles * p.nk;
     p.P = std::max<long>(1, std::min<long>(512, p.G / 16));    // at least 16 K-steps per workgroup (each segment costs a 64 KB slab)
@@ -256,8 +434,8 @@ extern "C" size_t nsgp_cov_workspace_bytes(int cin, int h, int w, int kh, int kw
     const int Ho = (Hp - kh) / sh + 1, Wo = (Wp - kw) / sw + 1;
     if (Ho <= 0 || Wo <= 0) return 0;
     const int D = cin * kh * kw;
-    const CovPlan p = cov_plan(D, Ho * Wo);
-    return align256((size_t)cin * Hp * Wp * 4) + (size_t)(p.tiles + p.P) * BM * BN * 4;
+    const CovPlan p16 = cov_plan(D, Ho * Wo, F2_BK), p32 = cov_plan(D, Ho * Wo, BK);     // enough for either path
+    return align256((size_t)cin * Hp * Wp * 4) + (size_t)(p32.tiles + std::max(p16.P, p32.P)) * BM * BN * 4 + 256;
 }
 
 extern "C" int nsgp_cov_accumulate_conv2d(const float* x, int batch, int cin, int h, int w, int kh, int kw, int sh,
@@ -271,23 +449,41 @@ extern "C" int nsgp_cov_accumulate_conv2d(const float* x, int batch, int cin, in
     const int Hp = h + 2 * ph, Wp = w + 2 * pw;
     const int Ho = (Hp - kh) / sh + 1, Wo = (Wp - kw) / sw + 1;
     ConvGeom g{cin * kh * kw, Ho * Wo, Wo, kh, kw, sh, sw, Hp, Wp};
-    const CovPlan p = cov_plan(g.D, g.L);
+    // the split path costs two extra tiny launches (clear + amax): measured worth it from ~10^4 (tile, k32-step) units on
+    const CovPlan p32 = cov_plan(g.D, g.L, BK);
+    const bool split = g_cov_split == 2 || (g_cov_split == 1 && p32.G >= 10000);
+    const CovPlan p = cov_plan(g.D, g.L, split ? F2_BK : BK);
     float* xm = static_cast<float*>(workspace);
     float* slabs = reinterpret_cast<float*>(static_cast<char*>(workspace) + align256((size_t)cin * Hp * Wp * 4));
+    unsigned* amax = reinterpret_cast<unsigned*>(static_cast<char*>(workspace) + need - 256);
     const long n_img = (long)cin * Hp * Wp;
     if (batch == 1 && ph == 0 && pw == 0) xm = const_cast<float*>(x);   // the image IS its own batch mean: no copy (all 1x1 convs at batch 1)
     else hipLaunchKernelGGL(nsgp_batch_mean_pad_kernel, dim3((unsigned)std::min<long>(4096, (n_img + 255) / 256)), dim3(256), 0, stream,
                        x, batch, cin, h, w, ph, pw, xm);
     NSGP_LAUNCH_CHECK();
-    NSGP_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(nsgp_cov_syrk_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, SMEM_BYTES));
-    hipLaunchKernelGGL(nsgp_cov_syrk_kernel, dim3((unsigned)p.P), dim3(THREADS), SMEM_BYTES, stream, xm, g, p.nk, p.G, slabs);
+    if (split) {
+        NSGP_HIP(hipMemsetAsync(amax, 0, sizeof(unsigned), stream));
+        hipLaunchKernelGGL(nsgp_amax_kernel, dim3((unsigned)std::min<long>(1024, (n_img + 255) / 256)), dim3(256), 0, stream, xm, n_img, amax);
+        NSGP_LAUNCH_CHECK();
+        NSGP_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(nsgp_cov_syrk_f16_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, F2_SMEM_BYTES));
+        hipLaunchKernelGGL(nsgp_cov_syrk_f16_kernel, dim3((unsigned)p.P), dim3(THREADS), F2_SMEM_BYTES, stream, xm, g, p.nk, p.G, amax, slabs);
+    } else {
+        NSGP_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(nsgp_cov_syrk_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, SMEM_BYTES));
+        hipLaunchKernelGGL(nsgp_cov_syrk_kernel, dim3((unsigned)p.P), dim3(THREADS), SMEM_BYTES, stream, xm, g, p.nk, p.G, slabs);
+    }
     NSGP_LAUNCH_CHECK();
     int bands = 2;                                              // >= 256 reduce workgroups, bands of 64 .. 4 rows
     while (bands < 32 && p.tiles * bands < 256) bands *= 2;
     hipLaunchKernelGGL(nsgp_cov_reduce_kernel, dim3((unsigned)p.tiles, bands), dim3(256), 0, stream, slabs, g.D, p.nk, p.G, p.P,
-                       BM / bands, cov, accumulate);
+                       BM / bands, cov, accumulate, split ? amax : nullptr);
     NSGP_LAUNCH_CHECK();
     return NSGP_OK;
+}
+
+extern "C" int nsgp_cov_set_split_mfma(int mode) {
+    const int prev = g_cov_split;
+    g_cov_split = mode < 0 ? 0 : (mode > 2 ? 2 : mode);
+    return prev;
 }
 
 extern "C" int nsgp_cov_accumulate_linear(const float* x, int batch, int features, float* cov, int accumulate, void* stream_) {

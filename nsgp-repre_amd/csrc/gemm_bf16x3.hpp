@@ -157,7 +157,7 @@ __device__ __forceinline__ void gemm_tile_bf16x3(const float* __restrict__ A, lo
 }
 
 // P [K x N] fp32 row-major -> the split terms of its transpose, layout [n][k/8][term][8] bf16 (once per projector per task)
-__global__ __launch_bounds__(256) void nsgp_split_transpose_bf16x3_kernel(const float* __restrict__ P, int K, int N, __bf16* __restrict__ Bt) {
+static __global__ __launch_bounds__(256) void nsgp_split_transpose_bf16x3_kernel(const float* __restrict__ P, int K, int N, __bf16* __restrict__ Bt) {
     __shared__ float tile[32][33];
     const int k0 = blockIdx.y * 32, n0 = blockIdx.x * 32;
     const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;      // 32 x 8

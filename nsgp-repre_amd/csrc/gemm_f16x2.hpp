@@ -140,7 +140,7 @@ __device__ __forceinline__ void gemm_tile_f16x2(const float* __restrict__ A, lon
 }
 
 // P [K x N] fp32 row-major -> the two fp16 terms of scale * P^T, layout [n][k/8][term][8] (once per projector per task)
-__global__ __launch_bounds__(256) void nsgp_split_transpose_f16x2_kernel(const float* __restrict__ P, int K, int N, float scale,
+static __global__ __launch_bounds__(256) void nsgp_split_transpose_f16x2_kernel(const float* __restrict__ P, int K, int N, float scale,
                                                                          _Float16* __restrict__ Bt) {
     __shared__ float tile[32][33];
     const int k0 = blockIdx.y * 32, n0 = blockIdx.x * 32;

@@ -119,6 +119,12 @@ def cov_accumulate_conv2d(x: torch.Tensor, kernel_size, stride, padding, cov: to
     return cov
 
 
+def cov_set_split_mfma(mode: int) -> int:
+    """Select the covariance SYRK's matrix-core path: 0 = fp32 MFMA, 1 = auto (default: the two-term fp16 split for layers
+    large enough to repay its extra launches), 2 = always the split.  Returns the previous setting."""
+    return int(_lib.load_library().nsgp_cov_set_split_mfma(int(mode)))
+
+
 def cov_workspace_bytes(cin, H, W, kernel_size, stride, padding) -> int:
     lib = _lib.load_library()
     return lib.nsgp_cov_workspace_bytes(cin, H, W, kernel_size[0], kernel_size[1], stride[0], stride[1],

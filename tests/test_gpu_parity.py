@@ -204,15 +204,25 @@ def test_g3_covariance_vs_golden(N, dev, golden_dir):
 @pytest.mark.parametrize("cin,k,s,p,hw,B", [(64, (1, 1), (1, 1), (0, 0), (50, 84), 2), (32, (3, 3), (1, 1), (1, 1), (25, 42), 1),
                                             (16, (3, 3), (2, 2), (1, 1), (50, 84), 2), (3, (7, 7), (2, 2), (3, 3), (64, 96), 1),
                                             (256, (1, 1), (1, 1), (0, 0), (13, 21), 1)])
-def test_covariance_vs_oracle_mid_sizes(N, dev, cin, k, s, p, hw, B):
+@pytest.mark.parametrize("mode", [0, 2])
+def test_covariance_vs_oracle_mid_sizes(N, dev, cin, k, s, p, hw, B, mode):
+    """Both matrix-core paths of the SYRK (0 = fp32 MFMA, 2 = two-term fp16 split forced; the default picks by size)."""
     from nsgp_repre_amd import ops
     x = torch.randn(B, cin, *hw, generator=torch.Generator().manual_seed(cin)).abs()
     ref = O.cov_conv2d(x, k, s, p)
-    cov = ops.cov_accumulate_conv2d(x.to(dev), k, s, p)
-    assert _rel(cov, ref) <= REL
-    cov = ops.cov_accumulate_conv2d(x.to(dev), k, s, p, cov)  # second batch accumulates
-    assert _rel(cov, ref + ref) <= REL
-    assert torch.equal(cov, cov.t().contiguous())
+    prev = ops.cov_set_split_mfma(mode)
+    try:
+        cov = ops.cov_accumulate_conv2d(x.to(dev), k, s, p)
+        assert _rel(cov, ref) <= REL
+        cov = ops.cov_accumulate_conv2d(x.to(dev), k, s, p, cov)  # second batch accumulates
+        assert _rel(cov, ref + ref) <= REL
+        assert torch.equal(cov, cov.t().contiguous())
+        # activations 1e+4 / 1e-6 times the usual size, and all zeros: the per-layer fp16 scale follows
+        for f in (1e4, 1e-6, 0.0):
+            c2 = ops.cov_accumulate_conv2d((x * f).to(dev), k, s, p)
+            assert torch.isfinite(c2).all() and _rel(c2, ref * f * f) <= REL
+    finally:
+        ops.cov_set_split_mfma(prev)
 
 
 # ------------------------------------------------------------------ a15 prototypes
