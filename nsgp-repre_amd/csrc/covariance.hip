@@ -174,9 +174,17 @@ __global__ __launch_bounds__(256, 2) void nsgp_cov_syrk_kernel(const float* __re
 // 8*(t&1) .. +7 of each operand as fp32 and splits them while writing to LDS.
 __global__ __launch_bounds__(256) void nsgp_amax_kernel(const float* __restrict__ x, long n, unsigned* __restrict__ out) {
     float am = 0.0f;
-    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) am = fmaxf(am, fabsf(x[i]));
+    const long n4 = (((uintptr_t)x & 15u) == 0) ? n / 4 : 0;      // float4 body when the base is 16-byte aligned
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
+        const f32x4 q = *(const gf32x4*)(x + 4 * i);
+        am = fmaxf(fmaxf(am, fmaxf(fabsf(q[0]), fabsf(q[1]))), fmaxf(fabsf(q[2]), fabsf(q[3])));
+    }
+    for (long i = 4 * n4 + (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) am = fmaxf(am, fabsf(as_global(x)[i]));
     for (int off = 32; off > 0; off >>= 1) am = fmaxf(am, __shfl_xor(am, off, 64));
-    if ((threadIdx.x & 63) == 0) atomicMax(out, __float_as_uint(am));
+    __shared__ float wmax[4];                                   // one atomic per workgroup: thousands of them on one address serialise
+    if ((threadIdx.x & 63) == 0) wmax[threadIdx.x >> 6] = am;
+    __syncthreads();
+    if (threadIdx.x == 0) atomicMax(out, __float_as_uint(fmaxf(fmaxf(wmax[0], wmax[1]), fmaxf(wmax[2], wmax[3]))));
 }
 
 struct Patch8 {
@@ -463,7 +471,7 @@ extern "C" int nsgp_cov_accumulate_conv2d(const float* x, int batch, int cin, in
     NSGP_LAUNCH_CHECK();
     if (split) {
         NSGP_HIP(hipMemsetAsync(amax, 0, sizeof(unsigned), stream));
-        hipLaunchKernelGGL(nsgp_amax_kernel, dim3((unsigned)std::min<long>(1024, (n_img + 255) / 256)), dim3(256), 0, stream, xm, n_img, amax);
+        hipLaunchKernelGGL(nsgp_amax_kernel, dim3((unsigned)std::min<long>(512, (n_img / 4 + 255) / 256 + 1)), dim3(256), 0, stream, xm, n_img, amax);
         NSGP_LAUNCH_CHECK();
         NSGP_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(nsgp_cov_syrk_f16_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, F2_SMEM_BYTES));
         hipLaunchKernelGGL(nsgp_cov_syrk_f16_kernel, dim3((unsigned)p.P), dim3(THREADS), F2_SMEM_BYTES, stream, xm, g, p.nk, p.G, amax, slabs);
