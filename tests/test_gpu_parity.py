@@ -417,7 +417,8 @@ def _run_both(N, dev, groups_spec, shapes, transforms_cpu, steps=2, grad_views=N
     init = {n: torch.randn(s, generator=gen) * 0.05 for n, s in shapes.items()}
     params = {n: torch.nn.Parameter(init[n].clone().to(dev)) for n in shapes}
     groups = [dict(params=[params[n] for n in names], **hp) for names, hp in groups_spec]
-    opt = N.SGDNSCL(groups, lr=0.01, svd=True) if kind == "sgd" else N.AdamWNSCL(groups, lr=1e-3, svd=True)
+    opt = {"sgd": lambda: N.SGDNSCL(groups, lr=0.01, svd=True), "adamw": lambda: N.AdamWNSCL(groups, lr=1e-3, svd=True),
+           "adam": lambda: N.AdamNSCL(groups, lr=1e-3, svd=True)}[kind]()
     for g, (names, _) in zip(opt.param_groups, groups_spec):
         g["names"] = list(names)
     for n, P in transforms_cpu.items():
@@ -447,9 +448,9 @@ def _run_both(N, dev, groups_spec, shapes, transforms_cpu, steps=2, grad_views=N
                 O.sgd_nscl_step(list(names), [cpu[n] for n in names], [grads[n].clone() for n in names],
                                 [states[n] for n in names], transforms_cpu, **full)
             else:
-                O.adamw_nscl_step(list(names), [cpu[n] for n in names], [grads[n].clone() for n in names],
-                                  [states[n] for n in names], transforms_cpu, lr=g["lr"], betas=g["betas"], eps=g["eps"],
-                                  weight_decay=g["weight_decay"], amsgrad=g["amsgrad"])
+                (O.adamw_nscl_step if kind == "adamw" else O.adam_nscl_step)(
+                    list(names), [cpu[n] for n in names], [grads[n].clone() for n in names], [states[n] for n in names], transforms_cpu,
+                    lr=g["lr"], betas=g["betas"], eps=g["eps"], weight_decay=g["weight_decay"], amsgrad=g["amsgrad"])
     torch.cuda.synchronize()
     return opt, params, cpu, init
 
@@ -486,7 +487,7 @@ def test_split_projector_terms_sum_to_the_projector(N, dev):
 
 
 @pytest.mark.parametrize("split", ["bf16x3", "f16x2"])
-@pytest.mark.parametrize("kind", ["sgd", "sgd_nomomentum", "sgd_nesterov", "adamw"])
+@pytest.mark.parametrize("kind", ["sgd", "sgd_nomomentum", "sgd_nesterov", "adamw", "adam_amsgrad"])
 def test_split_mfma_steps_vs_oracle(N, dev, kind, split):
     """Both split projection paths against the CPU oracle under the same 1e-5 gate as the fp32 path: aligned layers run
     the split kernel, a ragged layer in the same plan stays on the generic fp32 tiles, a plain tensor is untouched.  The SGD
@@ -497,8 +498,9 @@ def test_split_mfma_steps_vs_oracle(N, dev, kind, split):
     names = list(shapes)
     tr = _proj_for(shapes, names[:4])
     hp = {"sgd": dict(lr=0.02, momentum=0.9, weight_decay=1e-4), "sgd_nomomentum": dict(lr=0.02, momentum=0.0, weight_decay=1e-4),
-          "sgd_nesterov": dict(lr=0.02, momentum=0.9, weight_decay=1e-4, nesterov=True), "adamw": dict(lr=1e-3, weight_decay=0.05)}[kind]
-    okind = "adamw" if kind == "adamw" else "sgd"
+          "sgd_nesterov": dict(lr=0.02, momentum=0.9, weight_decay=1e-4, nesterov=True), "adamw": dict(lr=1e-3, weight_decay=0.05),
+          "adam_amsgrad": dict(lr=1e-3, weight_decay=1e-4, amsgrad=True)}[kind]
+    okind = {"adamw": "adamw", "adam_amsgrad": "adam"}.get(kind, "sgd")
     opt, params, cpu, init = _run_both(N, dev, [(names, hp)], shapes, tr, steps=3, kind=okind, split_mfma=split)
     assert opt.uses_split_mfma() == split
     _check(params, cpu, init, f"{split}-{kind}")
