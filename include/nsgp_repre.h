@@ -40,6 +40,9 @@ const char* nsgp_last_error(void);
 /* Number of HIP devices visible / name of the current one ("" without a GPU). */
 int nsgp_device_count(void);
 int nsgp_device_arch(char* buf, int buflen);
+/* Test-run diagnostics (no reference counterpart): from now on a SIGABRT first writes the native call stack of the
+ * aborting thread to fd 2, then runs the handler that was installed before (e.g. Python's faulthandler).  Idempotent. */
+int nsgp_debug_install_abort_backtrace(void);
 
 /* ------------------------------------------------------------------------
  * Projected optimizer step  (K1 + K2 of SURVEY section 2.2)
@@ -115,6 +118,10 @@ size_t nsgp_plan_workspace_bytes(const nsgp_tensor_t* tensors, int n_tensors, in
  * for the plan's lifetime.  Allocates a few hundred KB of device/pinned memory. */
 int nsgp_plan_create(nsgp_plan_t** plan, const nsgp_tensor_t* tensors, int n_tensors,
                      int optimizer, void* workspace, size_t workspace_bytes);
+/* Waits for the plan's own launches (its per-step events), then releases its device tables, pinned ring and events.
+ * Returns NSGP_ERR_HIP (first failing call in nsgp_last_error) if any release fails; the plan is gone either way.
+ * Call it from the thread that drives the stream -- never from a finaliser (the Python layer parks handles of
+ * garbage-collected optimizers and releases them at its next explicit entry point). */
 int nsgp_plan_destroy(nsgp_plan_t* plan);
 
 /* One optimizer step.  `grads[i]` = p.grad.data of tensor i (device pointers in a HOST

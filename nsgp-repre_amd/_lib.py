@@ -34,6 +34,7 @@ SIGNATURES = {
     "nsgp_last_error": (C.c_char_p, []),
     "nsgp_device_count": (C.c_int, []),
     "nsgp_device_arch": (C.c_int, [C.c_char_p, C.c_int]),
+    "nsgp_debug_install_abort_backtrace": (C.c_int, []),
     "nsgp_plan_workspace_bytes": (C.c_size_t, [C.POINTER(TensorDesc), C.c_int, C.c_int]),
     "nsgp_plan_create": (C.c_int, [C.POINTER(C.c_void_p), C.POINTER(TensorDesc), C.c_int, C.c_int, C.c_void_p, C.c_size_t]),
     "nsgp_plan_destroy": (C.c_int, [C.c_void_p]),

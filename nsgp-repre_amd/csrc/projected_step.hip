@@ -691,19 +691,27 @@ extern "C" int nsgp_plan_create(nsgp_plan_t** out, const nsgp_tensor_t* tensors,
 
 extern "C" int nsgp_plan_destroy(nsgp_plan_t* P) {
     if (!P) return NSGP_OK;
+    // Every launch of this plan is followed by an event record on its stream (nsgp_plan_step): waiting for the used slots
+    // means no kernel still reads the tables, and no copy still reads the pinned ring, when they are released below.
+    hipError_t first = hipSuccess;
+    const char* what = "";
+    auto keep = [&](hipError_t e, const char* w) { if (e != hipSuccess && first == hipSuccess) { first = e; what = w; } };
+    for (int s = 0; s < NSLOT; ++s)
+        if (P->ev[s] && P->ev_used[s]) keep(hipEventSynchronize(P->ev[s]), "hipEventSynchronize");
     for (int s = 0; s < NSLOT; ++s) {
-        if (P->ev[s]) { (void)hipEventSynchronize(P->ev[s]); (void)hipEventDestroy(P->ev[s]); }
-        if (P->h_dyn[s]) (void)hipHostFree(P->h_dyn[s]);
-        if (P->d_dyn[s]) (void)hipFree(P->d_dyn[s]);
+        if (P->ev[s]) keep(hipEventDestroy(P->ev[s]), "hipEventDestroy");
+        if (P->h_dyn[s]) keep(hipHostFree(P->h_dyn[s]), "hipHostFree");
+        if (P->d_dyn[s]) keep(hipFree(P->d_dyn[s]), "hipFree(dyn)");
     }
-    for (hipEvent_t e : P->prof_ev) (void)hipEventDestroy(e);
-    if (P->d_amax) (void)hipFree(P->d_amax);
-    if (P->d_tensors) (void)hipFree(P->d_tensors);
-    if (P->d_layers) (void)hipFree(P->d_layers);
-    if (P->d_tiles) (void)hipFree(P->d_tiles);
-    if (P->d_chunks) (void)hipFree(P->d_chunks);
-    if (P->d_chunks_lr) (void)hipFree(P->d_chunks_lr);
+    for (hipEvent_t e : P->prof_ev) keep(hipEventDestroy(e), "hipEventDestroy(profile)");
+    if (P->d_amax) keep(hipFree(P->d_amax), "hipFree(amax)");
+    if (P->d_tensors) keep(hipFree(P->d_tensors), "hipFree(tensors)");
+    if (P->d_layers) keep(hipFree(P->d_layers), "hipFree(layers)");
+    if (P->d_tiles) keep(hipFree(P->d_tiles), "hipFree(tiles)");
+    if (P->d_chunks) keep(hipFree(P->d_chunks), "hipFree(chunks)");
+    if (P->d_chunks_lr) keep(hipFree(P->d_chunks_lr), "hipFree(chunks_lr)");
     delete P;
+    if (first != hipSuccess) return fail(NSGP_ERR_HIP, "nsgp_plan_destroy: %s failed: %s", what, hipGetErrorString(first));
     return NSGP_OK;
 }
 
@@ -877,6 +885,43 @@ extern "C" int nsgp_project(const float* a, const float* proj, float* out, int r
 }
 
 // ---- misc ABI -----------------------------------------------------------------
+// Diagnostics for the GPU test runs: a process that dies with SIGABRT (the HIP / HSA runtimes abort() on a GPU memory
+// fault or a queue error, C++ on an escaped exception) normally leaves nothing but Python's "Fatal Python error: Aborted".
+// This handler writes the NATIVE call stack of the aborting thread to fd 2 first, then hands over to whatever handler was
+// installed before it (Python's faulthandler, or the default action).
+#include <execinfo.h>
+#include <signal.h>
+#include <unistd.h>
+static struct sigaction g_prev_abrt;
+static void abort_backtrace_handler(int sig, siginfo_t* info, void* uc) {
+    static const char head[] = "\n[nsgp_repre] SIGABRT -- native stack of the aborting thread:\n";
+    (void)!write(2, head, sizeof(head) - 1);
+    void* frames[64];
+    const int n = backtrace(frames, 64);
+    backtrace_symbols_fd(frames, n, 2);
+    if (g_prev_abrt.sa_flags & SA_SIGINFO) {
+        if (g_prev_abrt.sa_sigaction) { g_prev_abrt.sa_sigaction(sig, info, uc); return; }
+    } else if (g_prev_abrt.sa_handler != SIG_DFL && g_prev_abrt.sa_handler != SIG_IGN) {
+        g_prev_abrt.sa_handler(sig);
+        return;
+    }
+    signal(SIGABRT, SIG_DFL);
+    raise(SIGABRT);
+}
+extern "C" int nsgp_debug_install_abort_backtrace(void) {
+    static bool installed = false;
+    if (installed) return NSGP_OK;
+    void* warm[4];
+    (void)backtrace(warm, 4);                  // loads libgcc now: backtrace() must not dlopen inside a signal handler
+    struct sigaction sa;
+    std::memset(&sa, 0, sizeof(sa));
+    sa.sa_sigaction = abort_backtrace_handler;
+    sa.sa_flags = SA_SIGINFO | SA_NODEFER;
+    sigemptyset(&sa.sa_mask);
+    if (sigaction(SIGABRT, &sa, &g_prev_abrt) != 0) return fail(NSGP_ERR_INVALID, "sigaction(SIGABRT) failed");
+    installed = true;
+    return NSGP_OK;
+}
 extern "C" int nsgp_abi_version(void) { return NSGP_ABI_VERSION; }
 extern "C" const char* nsgp_last_error(void) { return err_buf(); }
 extern "C" int nsgp_device_count(void) {

@@ -14,6 +14,13 @@ def _stream():
     return C.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
+def _touched(t: torch.Tensor) -> torch.Tensor:
+    """A kernel wrote ``t`` through its raw pointer: bump the tensor's version counter, as an in-place torch op would, so
+    that whoever caches something derived from it (the optimizers' split projectors) sees the edit."""
+    torch.autograd.graph.increment_version(t)
+    return t
+
+
 def _dev(t: torch.Tensor, name: str, dtype=torch.float32):
     if not isinstance(t, torch.Tensor) or not t.is_cuda:
         raise RuntimeError(f"nsgp_repre_amd: `{name}` must be a GPU tensor (there is no CPU fallback)")
@@ -33,11 +40,12 @@ def project(a: torch.Tensor, proj: torch.Tensor, scale: float = 1.0, out: torch.
     cols = a.numel() // rows
     if proj.shape != (cols, cols):
         raise ValueError(f"projector shape {tuple(proj.shape)} does not match update [{rows} x {cols}]")
-    if out is None:
+    fresh = out is None
+    if fresh:
         out = torch.empty_like(a)
     _lib.check(lib.nsgp_project(_dev(a, "a"), _dev(proj, "proj"), _dev(out, "out"), rows, cols, float(scale),
                                 int(accumulate), _stream()), "nsgp_project")
-    return out
+    return out if fresh else _touched(out)
 
 
 def split_projector(P: torch.Tensor) -> torch.Tensor:
@@ -79,12 +87,15 @@ def build_projector(V: torch.Tensor, first_col: int, normalise: bool, out: torch
     D = V.shape[0]
     if V.shape != (D, D):
         raise ValueError("V must be square")
-    if out is None:
+    fresh = out is None
+    if fresh:
         out = torch.empty_like(V)
     nbytes = lib.nsgp_projector_scratch_bytes(D)
     scratch = torch.empty(nbytes, dtype=torch.uint8, device=V.device)
     _lib.check(lib.nsgp_build_projector(_dev(V, "V"), D, int(first_col), int(bool(normalise)), _dev(out, "P"),
                                         C.c_void_p(scratch.data_ptr()), nbytes, _stream()), "nsgp_build_projector")
+    if not fresh:
+        _touched(out)
     if return_norm:   # ||P||_F before the division (fp32, slot NORM_BLOCKS of the scratch), as a 0-d GPU tensor
         norm = scratch[1024 * 8:1024 * 8 + 4].view(torch.float32)[0] if normalise else torch.ones((), device=V.device)
         return out, norm
@@ -116,7 +127,7 @@ def cov_accumulate_conv2d(x: torch.Tensor, kernel_size, stride, padding, cov: to
                                               int(accumulate), C.c_void_p(workspace.data_ptr()),
                                               workspace.numel() * workspace.element_size(), _stream()),
                "nsgp_cov_accumulate_conv2d")
-    return cov
+    return _touched(cov) if accumulate else cov
 
 
 def cov_set_split_mfma(mode: int) -> int:
@@ -142,7 +153,7 @@ def cov_accumulate_linear(x: torch.Tensor, cov: torch.Tensor = None) -> torch.Te
         cov = torch.empty(Fd, Fd, dtype=torch.float32, device=x.device)
     _lib.check(lib.nsgp_cov_accumulate_linear(_dev(x, "x"), B, Fd, _dev(cov, "cov"), int(accumulate), _stream()),
                "nsgp_cov_accumulate_linear")
-    return cov
+    return _touched(cov) if accumulate else cov
 
 
 def sim_counts(feats: torch.Tensor, thr: float = 0.6):

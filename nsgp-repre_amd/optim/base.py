@@ -29,6 +29,29 @@ logger = logging.getLogger("nsgp_repre_amd")
 SPLIT_MFMA_DEFAULT = "f16x2"
 _SPLIT_KINDS = {False: 0, None: 0, "f32": 0, "bf16x3": 1, "f16x2": 2, True: 2}
 
+#: plan handles of optimizers that were garbage-collected without ``close()``.  ``__del__`` may run wherever the
+#: interpreter happens to collect -- on an autograd thread, in the middle of another test's backward -- so it makes NO HIP
+#: call: it parks the handles here and the next explicit, main-thread entry point (``step`` building plans, ``close``,
+#: ``release_collected_plans``) destroys them.
+_GRAVEYARD = []
+
+
+def release_collected_plans():
+    """Destroy the plans parked by ``__del__`` (device tables, pinned ring, events).  Returns how many were released;
+    a failing ``hipFree`` / ``hipEventDestroy`` is reported, not swallowed."""
+    if not _GRAVEYARD:
+        return 0
+    lib = _lib.load_library()
+    n = 0
+    while _GRAVEYARD:
+        handle = _GRAVEYARD.pop()
+        rc = lib.nsgp_plan_destroy(handle)
+        if rc != 0:
+            msg = lib.nsgp_last_error()
+            logger.error("nsgp_plan_destroy failed with code %d: %s", rc, msg.decode() if msg else "")
+        n += 1
+    return n
+
 
 class NSCLOptimizerBase(Optimizer):
     _kind = _lib.NSGP_OPT_SGD   # which C-ABI update rule
@@ -73,9 +96,20 @@ class NSCLOptimizerBase(Optimizer):
             self._basis, self.low_rank, self.mutate_grad, self.polish_basis = {}, False, True, True
             self.split_mfma, self._splits = SPLIT_MFMA_DEFAULT, {}
 
+    def close(self):
+        """Release the GPU resources of this optimizer's plans (device tables, pinned upload ring, events) NOW, on the
+        calling thread, with every HIP return code checked.  The runner calls it when a task's optimizer is done; the
+        optimizer stays usable (the next ``step`` builds fresh plans)."""
+        self._destroy_plans()
+        self._splits = {}
+        release_collected_plans()
+
     def __del__(self):
+        # no HIP call from a finaliser (see _GRAVEYARD): hand the raw handles over and forget them
         try:
-            self._destroy_plans()
+            for plan in getattr(self, "_plans", None) or []:
+                _GRAVEYARD.append(plan["handle"])
+            self._plans = []
         except Exception:
             pass
 
@@ -176,8 +210,22 @@ class NSCLOptimizerBase(Optimizer):
             V = (1.5 * V - 0.5 * (V @ G)).contiguous()
         P, norm = ops.build_projector(V, int(rank), normalise, return_norm=True)
         self.transforms[name] = P.detach_()
-        self._basis[name] = dict(V=V, rank=int(rank), norm=norm, P_ptr=P.data_ptr())
+        # the caches hold the projector OBJECT (not its address: the allocator hands a freed [D x D] block straight to the
+        # next layer's projector) and compare identity + version
+        self._basis[name] = dict(V=V, rank=int(rank), norm=norm, P=P, P_version=P._version)
+        self._splits.pop(name, None)
         self._plan_key = None  # new projector buffers -> new plan
+        self._fast = None
+
+    def invalidate_projector(self, name=None):
+        """Forget every derived copy (fp16 / bf16 split, low-rank basis link) of ``transforms[name]`` -- of all
+        projectors when ``name`` is None.  Needed only after rewriting a projector's memory behind torch's back (a raw
+        pointer write that does not bump the tensor's version counter); assigning a new tensor, an in-place torch op
+        or ``set_basis`` are detected on their own."""
+        for n in ([name] if name is not None else list(self._splits)):
+            self._splits.pop(n, None)
+        for n in ([name] if name is not None else list(self._basis)):
+            self._basis.pop(n, None)
         self._fast = None
 
     # ------------------------------------------------------------------ step
@@ -191,20 +239,24 @@ class NSCLOptimizerBase(Optimizer):
         raise NotImplementedError
 
     def _destroy_plans(self):
-        if self._plans:
-            lib = _lib.load_library()
-            for plan in self._plans:
-                lib.nsgp_plan_destroy(plan["handle"])
-        self._plans = []
-        self._workspaces = []
+        """Explicit, caller's-thread teardown (never from ``__del__``): each plan drains its own upload events before its
+        buffers go, and a failing HIP call raises."""
+        plans, self._plans = self._plans, []
         self._fast = None
+        if plans:
+            lib = _lib.load_library()
+            for plan in plans:
+                _lib.check(lib.nsgp_plan_destroy(plan["handle"]), "nsgp_plan_destroy")
+        self._workspaces = []       # after the plans: nsgp_plan_destroy has synchronised every launch that used them
 
     def _build_plans(self, entries):
         """entries: list of (group_index, name, p, state).  One plan per <= NSGP_MAX_HYPER groups."""
         lib = _lib.load_library()
         self._destroy_plans()
-        live = {(P.data_ptr(), P._version) for P in self.transforms.values() if isinstance(P, torch.Tensor)}
-        self._splits = {k: v for k, v in self._splits.items() if k[:2] in live}  # drop splits of replaced projectors
+        release_collected_plans()
+        # drop the split copies of projectors that were replaced or edited since they were made
+        self._splits = {n: c for n, c in self._splits.items()
+                        if self.transforms.get(n) is c["P"] and c["P"]._version == c["version"]}
         groups = sorted({gi for gi, *_ in entries})
         for lo in range(0, len(groups), _lib.NSGP_MAX_HYPER):
             gset = groups[lo:lo + _lib.NSGP_MAX_HYPER]
@@ -233,10 +285,11 @@ class NSCLOptimizerBase(Optimizer):
                     d.rows, d.cols = rows, cols
                     kind = _SPLIT_KINDS[self.split_mfma]
                     if kind and rows % 128 == 0 and cols % 128 == 0:
-                        sp, sc = self._split_of(P, kind)
+                        sp, sc = self._split_of(n, P, kind)
                         d.proj_split, d.split_kind, d.split_scale = sp.data_ptr(), kind, sc
                     b = self._basis.get(n)
-                    if self.low_rank and b is not None and b["P_ptr"] == P.data_ptr() and b["V"].is_contiguous():
+                    if (self.low_rank and b is not None and b["P"] is P and b["P_version"] == P._version
+                            and b["V"].is_contiguous()):
                         d.basis = b["V"].data_ptr()          # only for projectors this optimizer built itself
                         d.rank = int(b["rank"])
                         d.basis_scale = 1.0 / float(b["norm"])
@@ -251,13 +304,15 @@ class NSCLOptimizerBase(Optimizer):
             self._plans.append(dict(handle=handle, entries=sub, groups=gset,
                                     grads=(C.c_void_p * len(sub))(), hyper=(_lib.Hyper * len(gset))()))
 
-    def _split_of(self, P: torch.Tensor, kind: int):
-        """(split copy of ``P^T``, scale) of the given kind, cached per (storage, version, kind)."""
-        k = (P.data_ptr(), P._version, kind)
-        hit = self._splits.get(k)
-        if hit is None:
-            hit = self._splits[k] = (ops.split_projector(P), 1.0) if kind == 1 else ops.split_projector_f16(P)
-        return hit
+    def _split_of(self, name: str, P: torch.Tensor, kind: int):
+        """(split copy of ``P^T``, scale) of the given kind for ``transforms[name]``.  Cached per parameter name together
+        with the projector tensor itself: a hit needs the SAME tensor object at the SAME version (holding the reference
+        also keeps its address from being recycled while the copy is alive)."""
+        c = self._splits.get(name)
+        if c is None or c["P"] is not P or c["version"] != P._version or c["kind"] != kind:
+            split, scale = (ops.split_projector(P), 1.0) if kind == 1 else ops.split_projector_f16(P)
+            c = self._splits[name] = dict(P=P, version=P._version, kind=kind, split=split, scale=scale)
+        return c["split"], c["scale"]
 
     def uses_split_mfma(self):
         """The split kind every current plan runs its dense projection launch on: False, "bf16x3" or "f16x2"."""

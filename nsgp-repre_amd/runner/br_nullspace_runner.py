@@ -156,6 +156,8 @@ else:
                     self.optimizer.zero_grad()
                     loss.backward()
                     self.optimizer.step()
+            if hasattr(self.optimizer, "close"):
+                self.optimizer.close()       # the task's steps are over: release the plans' GPU resources here, not in a finaliser
             cov = self.cal_fea_in(self.model, cov_batches if cov_batches is not None else batches, cov_forward)
             rois = None
             if roi_forward is not None:

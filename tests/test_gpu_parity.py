@@ -747,3 +747,99 @@ def test_state_dict_round_trip_keeps_stepping_correctly(N, dev):
     torch.cuda.synchronize()
     for n in shapes:
         assert torch.equal(pa[n], pc[n]) and torch.equal(pa[n], pb[n]), n
+
+
+# ------------------------------------------------------------------ projector caches keyed on identity, explicit teardown
+@pytest.mark.parametrize("split", ["f16x2", "bf16x3", False])
+def test_rebuilding_projectors_on_a_stepped_optimizer(N, dev, split):
+    """Task t -> t+1 inside one process: ``get_eigens`` / ``get_transforms`` run again on an optimizer that has already
+    stepped.  ``set_basis`` frees the old projector of a layer just before the next layer's is allocated, so with several
+    layers of equal D the allocator hands old addresses to new projectors -- the split copies must follow the tensor
+    objects, not the addresses.  The oracle steps with the product's own current projectors (copied to the CPU), which
+    isolates the caching from the eigensolver."""
+    shapes = {"backbone.a.weight": (128, 256), "backbone.b.weight": (128, 256), "neck.c.weight": (256, 256),
+              "neck.d.weight": (128, 256, 1, 1), "backbone.e.weight": (256, 128, 1, 1), "neck.f.weight": (128, 128)}
+    names = list(shapes)
+    gen = torch.Generator().manual_seed(5)
+    init = {n: torch.randn(s, generator=gen) * 0.05 for n, s in shapes.items()}
+    params = {n: torch.nn.Parameter(init[n].clone().to(dev)) for n in names}
+    opt = N.SGDNSCL([params[n] for n in names], lr=0.02, momentum=0.9, weight_decay=1e-4, svd=True)
+    opt.param_groups[0]["names"] = names
+    opt.split_mfma = split
+    cpu = {n: init[n].clone() for n in names}
+    states = [dict() for _ in names]
+    hp = dict(lr=0.02, momentum=0.9, weight_decay=1e-4)
+    seen_ptrs = []
+    for task in range(3):
+        fea_in = {n: torch.from_numpy(I.covariance_like(int(np.prod(shapes[n][1:])), 300 + 17 * task + i, rows_mult=2)).to(dev)
+                  for i, n in enumerate(names)}
+        opt.get_eigens(fea_in)
+        opt.get_transforms(offset=0.0)
+        seen_ptrs.append({n: opt.transforms[n].data_ptr() for n in names})
+        tr_cpu = {n: opt.transforms[n].cpu() for n in names}
+        for _ in range(2):
+            grads = {n: torch.randn(shapes[n], generator=gen) for n in names}
+            for n in names:
+                params[n].grad = grads[n].clone().to(dev)
+            opt.step()
+            O.sgd_nscl_step(names, [cpu[n] for n in names], [grads[n].clone() for n in names], states, tr_cpu, **hp)
+        assert opt.uses_split_mfma() == split
+        torch.cuda.synchronize()
+        _check(params, cpu, init, f"task{task}")
+    # the scenario the cache has to survive did occur: some projector landed on an address an EARLIER projector
+    # (of another layer or task) had occupied
+    earlier = set()
+    recycled = False
+    for ptrs in seen_ptrs:
+        recycled |= any(p in earlier for p in ptrs.values())
+        earlier |= set(ptrs.values())
+    assert recycled, "the allocator never recycled a projector address: the test lost its point"
+    opt.close()
+    assert opt._plans == [] and opt._splits == {}
+    # still usable after close(): the next step builds fresh plans
+    for n in names:
+        params[n].grad = torch.zeros(shapes[n], device=dev)
+    opt.step()
+
+
+def test_raw_pointer_rewrite_of_a_projector_is_seen(N, dev):
+    """``ops.build_projector(out=P)`` writes P through its raw pointer; the wrapper bumps the tensor's version counter so
+    the cached fp16 split is redone (the version of such a tensor used to stay 0 for ever)."""
+    from nsgp_repre_amd import ops
+    D, rows = 256, 128
+    sv, V = O.eigens(torch.from_numpy(I.covariance_like(D, 41, rows_mult=2)))
+    Vd = V.to(dev).contiguous()
+    p = torch.nn.Parameter(torch.zeros(rows, D, device=dev))
+    opt = N.SGDNSCL([p], lr=1.0, momentum=0.0, svd=True)
+    opt.param_groups[0]["names"] = ["neck.w.weight"]
+    P = ops.build_projector(Vd, 40, False)
+    opt.transforms["neck.w.weight"] = P
+    g = torch.randn(rows, D, generator=torch.Generator().manual_seed(2))
+    p.grad = g.clone().to(dev)
+    opt.step()
+    v0 = P._version
+    ops.build_projector(Vd, 200, False, out=P)              # same tensor, same address, new contents
+    assert P._version > v0
+    before = p.detach().clone()
+    p.grad = g.clone().to(dev)
+    opt.step()
+    want = O.project_update(-g, P.cpu())
+    assert _rel(p.detach() - before, want) <= REL
+
+
+def test_collected_optimizers_release_their_plans_later(N, dev):
+    """``__del__`` makes no HIP call: the handles of a garbage-collected optimizer are parked and destroyed (with checked
+    return codes) at the next explicit entry point."""
+    import gc
+    from nsgp_repre_amd.optim import base
+    base.release_collected_plans()
+    p = torch.nn.Parameter(torch.zeros(64, 32, device=dev))
+    opt = N.SGDNSCL([p], lr=0.1, svd=True)
+    opt.param_groups[0]["names"] = ["x.weight"]
+    p.grad = torch.ones_like(p)
+    opt.step()
+    assert len(opt._plans) == 1
+    del opt
+    gc.collect()
+    assert len(base._GRAVEYARD) == 1
+    assert base.release_collected_plans() == 1 and base._GRAVEYARD == []

@@ -136,10 +136,7 @@ def test_two_task_run_keeps_old_features_fixed(N, dev):
     torch.manual_seed(1)
     data1 = [torch.randn(2, 3, 16, 16, device=dev) * torch.tensor([1.0, 0.1, 0.01], device=dev).view(1, 3, 1, 1) for _ in range(4)]
     data2 = [torch.randn(2, 3, 16, 16, device=dev) for _ in range(4)]
-    # The toy net's convolutions / batch norm run on torch's native kernels here: twice this round the process aborted (SIGABRT, no
-    # HIP error text) inside MIOpen's backward for these 16x16 shapes -- the first backward of the test, before any kernel of
-    # this repo had run in it.  The test is about the projected update, not about MIOpen.
-    with torch.backends.cudnn.flags(enabled=False), tempfile.TemporaryDirectory() as td:
+    with tempfile.TemporaryDirectory() as td:
         w1, w2 = os.path.join(td, "run_1"), os.path.join(td, "run_2")
         os.makedirs(w1); os.makedirs(w2)
         net = Net().to(dev)
