@@ -32,7 +32,7 @@ extern "C" {
 #define NSGP_ERR_WORKSPACE (-3) /* workspace too small */
 #define NSGP_ERR_LIMIT (-4)     /* a fixed capacity was exceeded (e.g. > NSGP_MAX_HYPER combos) */
 
-#define NSGP_ABI_VERSION 5
+#define NSGP_ABI_VERSION 6
 #define NSGP_MAX_HYPER 32 /* distinct hyper-parameter sets per plan step */
 
 int nsgp_abi_version(void);
@@ -82,13 +82,15 @@ typedef struct {
                            in 4*Cout*D*r FLOP instead of 2*Cout*D^2; otherwise the dense `proj` is used */
     float basis_scale;  /* 1/||P||_F for Frobenius-normalised projectors (SGD_NSCL.py:282-283), else 1 */
     int32_t split_kind; /* 0: no split copy; 1: proj_split holds the three-term bf16 split (nsgp_split_projector);
-                           2: the two-term fp16 split of split_scale * proj (nsgp_split_projector_f16) */
+                           2: the pre-tiled, column-scaled two-term fp16 split (nsgp_split_projector_f16) */
     const void* proj_split; /* optional split copy of proj^T.  When every 128-aligned projected tensor of a plan carries one
                            of the same kind, the dense projection runs on the low-precision matrix cores with fp32 accumulation
-                           and fp32-level error: kind 1 = six bf16 MFMAs per product (a0b0+a0b1+a1b0+a0b2+a1b1+a2b0),
-                           kind 2 = three fp16 MFMAs per product (a0b0+a0b1+a1b0) with one power-of-two scale per operand
-                           matrix (the update's is found by the elementwise launch of the same step).  NULL = fp32 MFMA */
-    float split_scale;  /* kind 2: the power of two proj was multiplied by before the split (largest |entry| in [2^13, 2^14)) */
+                           and fp32-level error PER OUTPUT ROW: kind 1 = six bf16 MFMAs per product (a0b0+a0b1+a1b0+a0b2+a1b1+a2b0),
+                           kind 2 = three fp16 MFMAs per product (a0b0+a0b1+a1b0) with one power-of-two scale per ROW of the
+                           update (found by the elementwise launch of the same step, which also writes the update's split
+                           copy into the plan workspace) and one per COLUMN of the projector (stored behind the split copy).
+                           NULL = fp32 MFMA */
+    float split_scale;  /* unused since ABI 6 (the fp16 split carries its per-column scales itself); keep 0 */
     int32_t reserved;
 } nsgp_tensor_t;
 
@@ -139,6 +141,9 @@ int nsgp_plan_lowrank_stats(const nsgp_plan_t* plan, int* n_lowrank, double* low
                             int* n_tiles_p1, int* n_tiles_p2);
 /* Kind of split the plan's dense projection launch uses: 0 = fp32 MFMA, 1 = three-term bf16, 2 = two-term fp16. */
 int nsgp_plan_uses_split_mfma(const nsgp_plan_t* plan);
+/* Dense-projection tiles of the plan by kernel: whole 128 x 128 tiles of the fp32-MFMA / bf16-split kernel, guarded 128 x 128
+ * tiles (ragged or misaligned layers, fp32 MFMA), and 256 x 128 (or 128 x 128) tiles of the fp16-split kernel. */
+int nsgp_plan_tile_counts(const nsgp_plan_t* plan, int* fast_128, int* generic_128, int* split_f16_256);
 
 /* Per-launch timing with HIP events recorded on the launch stream (measurement only): between
  * _begin and _end each nsgp_plan_step records 3 events; _end synchronises on them and returns
@@ -151,10 +156,13 @@ int nsgp_plan_profile_end(nsgp_plan_t* plan, int* n_steps, float* update_ms_avg,
  * proj: [D x D] fp32 row-major; out: >= nsgp_split_projector_bytes(D) bytes, 16-byte aligned; D % 8 == 0. */
 size_t nsgp_split_projector_bytes(int D);
 int nsgp_split_projector(const float* proj, int D, void* out, void* stream);
-/* Two-term fp16 split of scale * proj^T, layout [n][k/8][term][8] fp16, 4 bytes per element.  `scale` must be a power of two
- * that brings the largest |entry| of proj below 2^14 (fp16 overflows at 65504); the caller keeps it in split_scale. */
+/* Two-term fp16 split of diag(c) * proj^T with c[n] the power of two that brings the largest |entry| of projector column n
+ * into [2^13, 2^14) (fp16 overflows at 65504).  `out` (16-byte aligned, nsgp_split_projector_f16_bytes(D) bytes, D % 64 == 0):
+ *   [n / 64][k / 8][term][n % 64][8 fp16]   D*D*4 bytes -- 1 KiB planes, the unit the projection kernel moves by LDS-DMA
+ *   c[D] fp32, then 1/c[D] fp32.
+ * Two launches on `stream` (column maxima, split); once per projector per task. */
 size_t nsgp_split_projector_f16_bytes(int D);
-int nsgp_split_projector_f16(const float* proj, int D, float scale, void* out, void* stream);
+int nsgp_split_projector_f16(const float* proj, int D, void* out, void* stream);
 
 /* Stand-alone projection `out[rows x cols] (+)= scale * (a[rows x cols] @ proj[cols x cols])`
  * (SGD_NSCL.py:85-90 in isolation; accumulate=0 overwrites `out`).  Used by tests to check

@@ -60,9 +60,10 @@ SIGNATURES = {
     "nsgp_split_projector_bytes": (C.c_size_t, [C.c_int]),
     "nsgp_split_projector": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
     "nsgp_plan_uses_split_mfma": (C.c_int, [C.c_void_p]),
+    "nsgp_plan_tile_counts": (C.c_int, [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "nsgp_cov_set_split_mfma": (C.c_int, [C.c_int]),
     "nsgp_split_projector_f16_bytes": (C.c_size_t, [C.c_int]),
-    "nsgp_split_projector_f16": (C.c_int, [C.c_void_p, C.c_int, C.c_float, C.c_void_p, C.c_void_p]),
+    "nsgp_split_projector_f16": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
     "repre_sim_workspace_bytes": (C.c_size_t, [C.c_int, C.c_int]),
     "repre_sim_counts": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t,
                                    C.c_void_p]),

@@ -8,10 +8,13 @@
 //           weight decay, momentum / Adam moments, and `p += update` for tensors
 //           without a projector.  Projected tensors keep their update source for
 //           launch 2 (SGD: the momentum buffer or the mutated grad; Adam: workspace U).
-// Launch 2  nsgp_project_kernel   MFMA-bound. For every projected tensor
-//           p[Cout x D] += (scale * S[Cout x D]) @ P[D x D]  as 128x128 output tiles
-//           drawn from ONE cost-sorted tile table spanning all layers (longest K
-//           first = LPT list scheduling on the 256 CUs), interleaved so that tiles
+//           On the fp16-split path (the default) a workgroup of this launch owns 8 WHOLE ROWS of a
+//           projected tensor: it finds each row's largest |update|, and writes the update once more as
+//           the pre-tiled, row-scaled two-term fp16 split the projection streams (gemm_f16x2_v2.hpp).
+// Launch 2  nsgp_project_v2_kernel / nsgp_project_kernel   MFMA-bound. For every projected tensor
+//           p[Cout x D] += (scale * S[Cout x D]) @ P[D x D]  as 256x128 (fp16 split) or 128x128
+//           (fp32 MFMA, bf16 split) output tiles drawn from ONE cost-sorted tile table spanning all
+//           layers (longest K first = LPT list scheduling on the 256 CUs), interleaved so that tiles
 //           that share a P column panel land on the same XCD (blockIdx % 8).
 #include <algorithm>
 #include <cmath>
@@ -22,6 +25,7 @@
 #include "gemm_core.hpp"
 #include "gemm_bf16x3.hpp"
 #include "gemm_f16x2.hpp"
+#include "gemm_f16x2_v2.hpp"
 
 namespace nsgp {
 
@@ -35,6 +39,11 @@ struct TensorDev {
     long numel;
     int hyper;
     int projected;
+    // fp16-split path: the update of this tensor is also written as its pre-tiled row-scaled split (workspace), with 1/scale per row
+    void* a_split;
+    float* rinv;
+    int cols;
+    int pad;
 };
 
 struct LayerDev {
@@ -51,9 +60,12 @@ struct LayerDev {
     float* slabs;
     int rank, rpad, nsplit, kchunk;
     float basis_scale;
-    const void* split;     // split copy of proj^T: kind 1 = three bf16 terms (gemm_bf16x3.hpp), 2 = two pre-scaled fp16 terms (gemm_f16x2.hpp)
+    const void* split;     // split copy of proj^T: kind 1 = three bf16 terms (gemm_bf16x3.hpp), 2 = pre-tiled column-scaled fp16 pair (gemm_f16x2_v2.hpp)
     int split_kind;
-    float split_scale;     // kind 2: the power of two the projector was multiplied by before the split
+    int pad;
+    const float* cinv;     // kind 2: 1 / (power-of-two scale of each projector column), D floats behind the split copy
+    const void* a_split;   // kind 2: this step's update, pre-tiled row-scaled fp16 pair (written by the elementwise launch)
+    const float* rinv;     // kind 2: 1 / (scale of each update row)
 };
 
 struct TileDev {
@@ -65,7 +77,7 @@ constexpr int LR_KCHUNK_DEFAULT = 512;  // K extent of one low-rank phase-1 tile
 
 struct ChunkDev {
     int tensor;
-    int pad;
+    int band;    // 1: rows [start / cols, +8) of a projected tensor on the fp16-split path; 0: a linear chunk of CHUNK elements
     long start;
 };
 
@@ -107,26 +119,64 @@ __device__ __forceinline__ void adam_elem(float& p, float& g, float& m, float& v
     if (projected) u = upd; else p = p + upd;
 }
 
+// Row bookkeeping of a band workgroup: a thread walks its elements in steps of `stride` and needs the band-local row of
+// each (cols % 4 == 0, so a float4 never straddles rows).  One division per thread up front, increments afterwards.
+struct RowWalk {
+    int row, k, q, rm, cols;
+    __device__ __forceinline__ void init(long local, int stride, int cols_) {
+        cols = cols_;
+        row = (int)(local / cols_);
+        k = (int)(local - (long)row * cols_);
+        q = stride / cols_;
+        rm = stride - q * cols_;
+    }
+    __device__ __forceinline__ void next() {
+        row += q;
+        k += rm;
+        if (k >= cols) { k -= cols; ++row; }
+    }
+};
+
 template <int OPT>
 __global__ __launch_bounds__(256) void nsgp_update_kernel(const ChunkDev* __restrict__ chunks,
                                                           const TensorDev* __restrict__ tensors,
-                                                          const DynBlock* __restrict__ dyn, unsigned* __restrict__ amax) {
+                                                          const DynBlock* __restrict__ dyn) {
+    __shared__ unsigned s_rowmax[8];
+    __shared__ float s_rowscale[8];
     const ChunkDev c = chunks[blockIdx.x];
     const TensorDev T = tensors[c.tensor];
     const nsgp_hyper_t h = dyn->hyper[T.hyper];
     float* __restrict__ gp = dyn->grads[c.tensor];
-    const long end = (c.start + CHUNK < T.numel) ? c.start + CHUNK : T.numel;
+    const bool band = c.band != 0;                       // uniform per workgroup
+    const long span = band ? 8L * T.cols : (long)CHUNK;
+    const long end = (c.start + span < T.numel) ? c.start + span : T.numel;
     const bool proj = T.projected != 0;
     const bool vec = (((uintptr_t)T.p | (uintptr_t)gp | (uintptr_t)T.s0 | (uintptr_t)T.s1 | (uintptr_t)T.s2 |
                        (uintptr_t)T.u) & 15u) == 0;
     // the mutated gradient is the GEMM's A operand unless a non-Nesterov momentum buffer is
     bool wg = h.write_grad != 0;
     if (OPT == NSGP_OPT_SGD && proj && !(h.momentum != 0.0f && !h.nesterov)) wg = true;
-    // largest magnitude of what the projection will read as its A operand (fp16 split path: per-tensor scale)
+    // what the projection reads as its A operand: momentum buffer, mutated gradient, or Adam's update
     const bool a_is_buf = (OPT == NSGP_OPT_SGD) && h.momentum != 0.0f && !h.nesterov;
+    if (band) {
+        if (threadIdx.x < 8) s_rowmax[threadIdx.x] = 0u;
+        __syncthreads();
+    }
+    // band workgroups keep the largest |A| of the row they are in and hand it to LDS whenever the row changes
+    RowWalk rw;
     float am = 0.0f;
+    int cur_row = -1;
+    auto note = [&](float a0, float a1, float a2, float a3) {
+        if (rw.row != cur_row) {
+            if (cur_row >= 0) atomicMax(&s_rowmax[cur_row], __float_as_uint(am));
+            cur_row = rw.row;
+            am = 0.0f;
+        }
+        am = fmaxf(fmaxf(am, fmaxf(fabsf(a0), fabsf(a1))), fmaxf(fabsf(a2), fabsf(a3)));
+    };
     long i = c.start + (long)threadIdx.x * 4;
     if (vec) {
+        if (band) rw.init((long)threadIdx.x * 4, 256 * 4, T.cols);
         for (; i + 3 < end; i += 256 * 4) {
             float4 p4 = *reinterpret_cast<const float4*>(T.p + i);
             float4 g4 = *reinterpret_cast<const float4*>(gp + i);
@@ -138,9 +188,10 @@ __global__ __launch_bounds__(256) void nsgp_update_kernel(const ChunkDev* __rest
                     bv[0] = b4.x; bv[1] = b4.y; bv[2] = b4.z; bv[3] = b4.w;
                 }
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    sgd_elem(pv[e], gv[e], bv[e], h, proj);
-                    am = fmaxf(am, fabsf(a_is_buf ? bv[e] : gv[e]));
+                for (int e = 0; e < 4; ++e) sgd_elem(pv[e], gv[e], bv[e], h, proj);
+                if (band) {
+                    if (a_is_buf) note(bv[0], bv[1], bv[2], bv[3]); else note(gv[0], gv[1], gv[2], gv[3]);
+                    rw.next();
                 }
                 if (h.momentum != 0.0f) *reinterpret_cast<float4*>(T.s0 + i) = make_float4(bv[0], bv[1], bv[2], bv[3]);
                 if (wg && (h.weight_decay != 0.0f || (h.momentum != 0.0f && h.nesterov)))
@@ -156,10 +207,8 @@ __global__ __launch_bounds__(256) void nsgp_update_kernel(const ChunkDev* __rest
                     xv[0] = x4.x; xv[1] = x4.y; xv[2] = x4.z; xv[3] = x4.w;
                 }
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    adam_elem(pv[e], gv[e], mv[e], vv[e], xv[e], uv[e], h, proj);
-                    am = fmaxf(am, fabsf(uv[e]));
-                }
+                for (int e = 0; e < 4; ++e) adam_elem(pv[e], gv[e], mv[e], vv[e], xv[e], uv[e], h, proj);
+                if (band) { note(uv[0], uv[1], uv[2], uv[3]); rw.next(); }
                 *reinterpret_cast<float4*>(T.s0 + i) = make_float4(mv[0], mv[1], mv[2], mv[3]);
                 *reinterpret_cast<float4*>(T.s1 + i) = make_float4(vv[0], vv[1], vv[2], vv[3]);
                 if (h.amsgrad) *reinterpret_cast<float4*>(T.s2 + i) = make_float4(xv[0], xv[1], xv[2], xv[3]);
@@ -168,11 +217,12 @@ __global__ __launch_bounds__(256) void nsgp_update_kernel(const ChunkDev* __rest
                 else *reinterpret_cast<float4*>(T.p + i) = make_float4(pv[0], pv[1], pv[2], pv[3]);
             }
         }
-        // scalar tail of a tensor whose numel is not a multiple of 4
+        // scalar tail of a tensor whose numel is not a multiple of 4 (never a band: cols % 128 == 0 there)
         const long tail0 = end - ((end - c.start) & 3);
         i = tail0 + threadIdx.x;
     } else {
         i = c.start + threadIdx.x;
+        if (band) rw.init((long)threadIdx.x, 256, T.cols);
     }
     const long stride = vec ? end : 256;  // vec: at most 3 tail elements, one per thread
     for (; i < end; i += stride) {
@@ -180,23 +230,48 @@ __global__ __launch_bounds__(256) void nsgp_update_kernel(const ChunkDev* __rest
         if (OPT == NSGP_OPT_SGD) {
             float bv = (h.momentum != 0.0f) ? T.s0[i] : 0.0f;
             sgd_elem(pv, gv, bv, h, proj);
-            am = fmaxf(am, fabsf(a_is_buf ? bv : gv));
+            if (band && !vec) { const float a = a_is_buf ? bv : gv; note(a, a, a, a); rw.next(); }
             if (h.momentum != 0.0f) T.s0[i] = bv;
             if (wg && (h.weight_decay != 0.0f || (h.momentum != 0.0f && h.nesterov))) gp[i] = gv;
             if (!proj) T.p[i] = pv;
         } else {
             float mv = T.s0[i], vv = T.s1[i], xv = h.amsgrad ? T.s2[i] : 0.0f, uv;
             adam_elem(pv, gv, mv, vv, xv, uv, h, proj);
-            am = fmaxf(am, fabsf(uv));
+            if (band && !vec) { note(uv, uv, uv, uv); rw.next(); }
             T.s0[i] = mv; T.s1[i] = vv;
             if (h.amsgrad) T.s2[i] = xv;
             if (wg && h.weight_decay != 0.0f) gp[i] = gv;
             if (proj) T.u[i] = uv; else T.p[i] = pv;
         }
     }
-    if (amax && proj) {     // max is order-independent: the atomic keeps the step deterministic
-        for (int off = 32; off > 0; off >>= 1) am = fmaxf(am, __shfl_xor(am, off, 64));
-        if ((threadIdx.x & 63) == 0) atomicMax(amax + c.tensor, __float_as_uint(am));
+    if (!band) return;
+    // ---- band epilogue: row scales, then the update of these 8 rows once more as its pre-tiled two-term fp16 split.
+    // The A values were written to global memory just above by this workgroup (momentum buffer / mutated gradient / u):
+    // __syncthreads() makes them visible to the whole workgroup and they are still in this CU's cache hierarchy.
+    if (cur_row >= 0) atomicMax(&s_rowmax[cur_row], __float_as_uint(am));
+    __syncthreads();
+    const int row0 = (int)(c.start / T.cols);
+    if (threadIdx.x < 8) {
+        const float sc = f2_scale_from_amax_bits(s_rowmax[threadIdx.x]);
+        s_rowscale[threadIdx.x] = sc;
+        T.rinv[row0 + threadIdx.x] = 1.0f / sc;
+    }
+    __syncthreads();
+    const float* __restrict__ Asrc = (OPT == NSGP_OPT_SGD) ? (a_is_buf ? T.s0 : gp) : T.u;
+    const bool a_vec = ((uintptr_t)Asrc & 15u) == 0;
+    for (int id = threadIdx.x; id < T.cols; id += 256) {      // 8 rows x cols / 8 octets; 8 consecutive lanes = one full 128-B line per plane
+        const int r = id & 7, o = id >> 3;
+        const float* src = Asrc + c.start + (long)r * T.cols + o * 8;
+        f32x4 lo, hi;
+        if (a_vec) {
+            lo = *(const gf32x4*)src;
+            hi = *(const gf32x4*)(src + 4);
+        } else {
+            const gfloat* g = as_global(src);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { lo[e] = g[e]; hi[e] = g[4 + e]; }
+        }
+        v2_store_pieces(T.a_split, row0 + r, o, T.cols, lo, hi, s_rowscale[r]);
     }
 }
 
@@ -225,7 +300,7 @@ __device__ __forceinline__ void store_tile(float* __restrict__ C, long ldc, int 
 template <int OPT, bool FAST, int SPLIT = 0>
 __global__ __launch_bounds__(256, 2) void nsgp_project_kernel(const TileDev* __restrict__ tiles,
                                                               const LayerDev* __restrict__ layers,
-                                                              const DynBlock* __restrict__ dyn, const unsigned* __restrict__ amax = nullptr) {
+                                                              const DynBlock* __restrict__ dyn) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const TileDev t = tiles[blockIdx.x];
     const LayerDev L = layers[t.layer];
@@ -245,11 +320,7 @@ __global__ __launch_bounds__(256, 2) void nsgp_project_kernel(const TileDev* __r
     zero_acc(acc);
     // the grad pointer is only known at step time: a misaligned one (e.g. a view into a flat
     // bucket) takes the guarded scalar loader for the A operand only
-    if (SPLIT == 2 && ((uintptr_t)A & 15u) == 0) {  // three fp16 MFMAs per fp32-equivalent product (gemm_f16x2.hpp)
-        const float sa = f2_scale_from_amax_bits(amax[L.tensor]);
-        gemm_tile_f16x2(A, L.cols, static_cast<const _Float16*>(L.split), L.cols, t.m0, t.n0, sa, smem, acc);
-        scale = scale * (1.0f / sa) * (1.0f / L.split_scale);     // both powers of two: exact
-    } else if (SPLIT == 1 && ((uintptr_t)A & 15u) == 0)          // six bf16 MFMAs per fp32-equivalent product (gemm_bf16x3.hpp)
+    if (SPLIT == 1 && ((uintptr_t)A & 15u) == 0)                 // six bf16 MFMAs per fp32-equivalent product (gemm_bf16x3.hpp)
         gemm_tile_bf16x3(A, L.cols, static_cast<const __bf16*>(L.split), L.cols, t.m0, t.n0, smem, acc);
     else if (!FAST || ((uintptr_t)A & 15u) == 0)
         gemm_tile<FAST, FAST, false>(A, L.cols, L.proj, L.cols, L.rows, L.cols, L.cols, t.m0, t.n0, smem, acc);
@@ -272,6 +343,38 @@ __global__ __launch_bounds__(256, 2) void nsgp_project_kernel(const TileDev* __r
     } else {
         store_tile<FAST, true>(L.p, L.cols, L.rows, L.cols, t.m0, t.n0, acc, scale);
     }
+}
+
+// fp16-split path (gemm_f16x2_v2.hpp): p += scale * rinv[m] * cinv[n] * (A_split x B_split), 256 x 128 tiles (t.pad = 4 row
+// blocks) or 128 x 128 (t.pad = 2), 512 threads, one workgroup per CU.
+template <int OPT>
+__global__ __launch_bounds__(V2_THREADS, 2) void nsgp_project_v2_kernel(const TileDev* __restrict__ tiles,
+                                                                        const LayerDev* __restrict__ layers,
+                                                                        const DynBlock* __restrict__ dyn) {
+    extern __shared__ __attribute__((aligned(16))) char smem_c[];
+    const TileDev t = tiles[blockIdx.x];
+    const LayerDev L = layers[t.layer];
+    const float scale = (OPT == NSGP_OPT_SGD) ? -dyn->hyper[L.hyper].lr : 1.0f;   // update = -(lr * grad), SGD_NSCL.py:413
+    f32x16 acc[2][2];
+    zero_acc(acc);
+    if (t.pad == 4) gemm_tile_f16x2_v2<4>(L.a_split, t.m0 >> 6, L.split, t.n0 >> 6, L.cols, smem_c, acc);
+    else gemm_tile_f16x2_v2<2>(L.a_split, t.m0 >> 6, L.split, t.n0 >> 6, L.cols, smem_c, acc);
+    if ((int)(threadIdx.x >> 6) >= 2 * t.pad) return;      // 128-row tile: waves 4-7 only moved data
+    float* smem = reinterpret_cast<float*>(smem_c);
+    acc_to_lds(smem, acc);
+    __builtin_amdgcn_s_waitcnt(0xc07f);                    // lgkmcnt(0): this wave's own LDS writes have landed
+    const int lane = threadIdx.x & 63, wn = (threadIdx.x >> 6) & 1;
+    const f32x4 ci = *(const gf32x4*)(L.cinv + t.n0 + wn * 64 + 4 * (lane & 15));    // this lane's four columns, every pass
+    for_each_row4(smem, [&](int r, int col, float4 v) {
+        const float ri = L.rinv[t.m0 + r];
+        gf32x4* pp = (gf32x4*)(L.p + (long)(t.m0 + r) * L.cols + t.n0 + col);
+        f32x4 pv = *pp;
+        pv[0] = pv[0] + scale * (ri * (ci[0] * v.x));      // ri, ci: powers of two -- exact
+        pv[1] = pv[1] + scale * (ri * (ci[1] * v.y));
+        pv[2] = pv[2] + scale * (ri * (ci[2] * v.z));
+        pv[3] = pv[3] + scale * (ri * (ci[3] * v.w));
+        *pp = pv;
+    });
 }
 
 template <bool FAST>
@@ -401,6 +504,12 @@ static int enable_big_lds(K kernel) {
     return NSGP_OK;
 }
 
+template <typename K>
+static int enable_v2_lds(K kernel) {
+    NSGP_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, V2_SMEM_BYTES));
+    return NSGP_OK;
+}
+
 }  // namespace nsgp
 
 using namespace nsgp;
@@ -411,8 +520,8 @@ struct nsgp_plan {
     int n_layers = 0;
     int n_chunks = 0;
     int n_tiles_fast = 0, n_tiles_generic = 0;
+    int n_tiles_v2 = 0;         // 256 x 128 / 128 x 128 tiles of the fp16-split kernel (split_kind 2); they replace the fast tiles
     int split_kind = 0;         // dense fast tiles: 0 fp32 MFMA, 1 three-term bf16 split, 2 two-term fp16 split
-    unsigned* d_amax = nullptr; // [NSLOT][n_tensors] largest |A| per tensor, written by the elementwise launch (kind 2)
     double gemm_flops = 0, bytes = 0;
     TensorDev* d_tensors = nullptr;
     LayerDev* d_layers = nullptr;
@@ -434,6 +543,10 @@ struct nsgp_plan {
 
 static bool tensor_fast(const nsgp_tensor_t& t) {
     return t.rows % BM == 0 && t.cols % BN == 0 && t.cols % BK == 0 && aligned16(t.proj);
+}
+// the fp16-split kernel takes a layer when it has the fast shape and carries a kind-2 split copy of its projector
+static bool tensor_v2(const nsgp_tensor_t& t) {
+    return tensor_fast(t) && t.split_kind == 2 && t.proj_split && aligned16(t.proj_split) && aligned16(t.param) && aligned16(t.state0);
 }
 
 // low-rank form: needs the fast shape, an aligned basis, and r <= D/4 (else the dense GEMM is cheaper)
@@ -475,6 +588,7 @@ extern "C" size_t nsgp_plan_workspace_bytes(const nsgp_tensor_t* tensors, int n,
         const nsgp_tensor_t& t = tensors[i];
         if (!t.proj) continue;
         if (optimizer == NSGP_OPT_ADAM) s += pad256((size_t)t.numel * 4);
+        if (tensor_v2(t) && !tensor_lowrank(t)) s += pad256(v2_operand_bytes(t.rows, t.cols)) + pad256((size_t)t.rows * 4);
         if (tensor_lowrank(t)) s += pad256((size_t)t.rows * lr_rpad(t.rank) * 4) * (1 + lr_nsplit(t.cols, 256));  // worst case split
     }
     return s;
@@ -505,7 +619,7 @@ extern "C" int nsgp_plan_create(nsgp_plan_t** out, const nsgp_tensor_t* tensors,
         if (t.hyper < 0 || t.hyper >= NSGP_MAX_HYPER) return fail(NSGP_ERR_LIMIT, "tensor %d: hyper index %d", i, t.hyper);
         if (!t.state0) return fail(NSGP_ERR_INVALID, "tensor %d: state0 is null", i);
         if (optimizer == NSGP_OPT_ADAM && !t.state1) return fail(NSGP_ERR_INVALID, "tensor %d: Adam needs state1", i);
-        TensorDev d{t.param, t.state0, t.state1, t.state2, nullptr, (long)t.numel, t.hyper, t.proj ? 1 : 0};
+        TensorDev d{t.param, t.state0, t.state1, t.state2, nullptr, (long)t.numel, t.hyper, t.proj ? 1 : 0, nullptr, nullptr, t.cols, 0};
         if (t.proj) {
             if (t.rows <= 0 || t.cols <= 0 || (int64_t)t.rows * t.cols != t.numel)
                 return fail(NSGP_ERR_INVALID, "tensor %d: rows*cols (%d*%d) != numel %lld", i, t.rows, t.cols,
@@ -515,7 +629,17 @@ extern "C" int nsgp_plan_create(nsgp_plan_t** out, const nsgp_tensor_t* tensors,
                 ws_off += ((size_t)t.numel * 4 + 255) & ~(size_t)255;
             }
             LayerDev L{t.param, t.state0, d.u, t.proj, i, t.rows, t.cols, t.hyper, nullptr, nullptr, nullptr, 0, 0, 0, 0, 1.0f,
-                       t.proj_split, t.split_kind, t.split_scale};
+                       t.proj_split, t.split_kind, 0, nullptr, nullptr, nullptr};
+            if (tensor_v2(t) && !tensor_lowrank(t)) {
+                // the split copy carries its column scales behind the planes: [D x D x 4 B][scale: D floats][1/scale: D floats]
+                L.cinv = reinterpret_cast<const float*>(static_cast<const char*>(t.proj_split) + v2_operand_bytes(t.cols, t.cols)) + t.cols;
+                d.a_split = static_cast<char*>(workspace) + ws_off;
+                ws_off += pad256(v2_operand_bytes(t.rows, t.cols));
+                d.rinv = reinterpret_cast<float*>(static_cast<char*>(workspace) + ws_off);
+                ws_off += pad256((size_t)t.rows * 4);
+                L.a_split = d.a_split;
+                L.rinv = d.rinv;
+            }
             if (tensor_lowrank(t)) {
                 L.basis = t.basis;
                 L.rank = t.rank;
@@ -533,7 +657,7 @@ extern "C" int nsgp_plan_create(nsgp_plan_t** out, const nsgp_tensor_t* tensors,
             ld.push_back(L);
             layer_fast.push_back(tensor_fast(t) && aligned16(t.param) && aligned16(t.state0) ? 1 : 0);
             if (layer_fast.back() && !tensor_lowrank(t)) {
-                const bool ok = t.proj_split && aligned16(t.proj_split) && (t.split_kind == 1 || (t.split_kind == 2 && t.split_scale > 0.0f));
+                const bool ok = t.proj_split && aligned16(t.proj_split) && (t.split_kind == 1 || t.split_kind == 2);
                 if (!ok) all_split = false;
                 else if (split_kind == 0) split_kind = t.split_kind;
                 else if (split_kind != t.split_kind) all_split = false;
@@ -543,8 +667,14 @@ extern "C" int nsgp_plan_create(nsgp_plan_t** out, const nsgp_tensor_t* tensors,
         }
         bytes += 5.0 * 4.0 * (double)t.numel;
         td[i] = d;
-        for (long s = 0; s < t.numel; s += CHUNK) cd.push_back(ChunkDev{i, 0, s});
+        if (d.a_split) for (long s = 0; s < t.numel; s += 8L * t.cols) cd.push_back(ChunkDev{i, 1, s});   // 8-row bands
+        else for (long s = 0; s < t.numel; s += CHUNK) cd.push_back(ChunkDev{i, 0, s});
     }
+    // longest workgroups first (a band of a 4608-wide layer is 36,864 elements, a linear chunk 16,384)
+    std::stable_sort(cd.begin(), cd.end(), [&](const ChunkDev& a, const ChunkDev& b) {
+        const long la = a.band ? 8L * tensors[a.tensor].cols : CHUNK, lb = b.band ? 8L * tensors[b.tensor].cols : CHUNK;
+        return la > lb;
+    });
 
     // ---- tile table.  Layers are grouped by K (= cols, the per-tile cost) in descending order, so
     // the hardware's in-order dispatch of blockIdx does longest-first list scheduling on the 256
@@ -555,9 +685,12 @@ extern "C" int nsgp_plan_create(nsgp_plan_t** out, const nsgp_tensor_t* tensors,
     std::vector<int> order(ld.size());
     for (size_t i = 0; i < order.size(); ++i) order[i] = (int)i;
     std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return ld[a].cols > ld[b].cols; });
-    std::vector<TileDev> fast_tiles, gen_tiles;
-    for (int pass = 0; pass < 2; ++pass) {
-        std::vector<TileDev>& dst = pass == 0 ? fast_tiles : gen_tiles;
+    // three tile classes: 0 = fast 128 x 128 (fp32 MFMA / bf16 split), 1 = generic guarded 128 x 128, 2 = fp16-split 256 x 128
+    std::vector<TileDev> fast_tiles, gen_tiles, v2_tiles;
+    auto layer_class = [&](int li) { return ld[li].a_split ? 2 : (layer_fast[li] ? 0 : 1); };
+    for (int pass = 0; pass < 3; ++pass) {
+        std::vector<TileDev>& dst = pass == 0 ? fast_tiles : (pass == 1 ? gen_tiles : v2_tiles);
+        const int TM = pass == 2 ? 4 * V2_BLOCK_ROWS : BM;
         size_t g0 = 0;
         while (g0 < order.size()) {
             size_t g1 = g0;
@@ -570,17 +703,19 @@ extern "C" int nsgp_plan_create(nsgp_plan_t** out, const nsgp_tensor_t* tensors,
             long group_tiles = 0;
             for (size_t oi = g0; oi < g1; ++oi) {
                 const int li = order[oi];
-                if ((layer_fast[li] != 0) != (pass == 0) || ld[li].rank > 0) continue;
-                group_tiles += (long)((ld[li].rows + BM - 1) / BM) * ((ld[li].cols + BN - 1) / BN);
+                if (layer_class(li) != pass || ld[li].rank > 0) continue;
+                group_tiles += (long)((ld[li].rows + TM - 1) / TM) * ((ld[li].cols + BN - 1) / BN);
             }
             long seen = 0;
             for (size_t oi = g0; oi < g1; ++oi) {
                 const int li = order[oi];
-                if ((layer_fast[li] != 0) != (pass == 0) || ld[li].rank > 0) continue;
-                const int mb = (ld[li].rows + BM - 1) / BM, nb = (ld[li].cols + BN - 1) / BN;
+                if (layer_class(li) != pass || ld[li].rank > 0) continue;
+                const int mb = (ld[li].rows + TM - 1) / TM, nb = (ld[li].cols + BN - 1) / BN;
                 for (int j = 0; j < nb; ++j) {
                     const int qi = (int)std::min<long>(7, seen * 8 / std::max<long>(group_tiles, 1));
-                    for (int m = 0; m < mb; ++m) q[qi].push_back(TileDev{li, m * BM, j * BN, 0});
+                    // class 2: pad = row blocks of this tile (4, or 2 for a 128-row layer / remainder)
+                    for (int m = 0; m < mb; ++m)
+                        q[qi].push_back(TileDev{li, m * TM, j * BN, pass == 2 ? std::min(4, (ld[li].rows - m * TM) / V2_BLOCK_ROWS) : 0});
                     seen += mb;
                 }
             }
@@ -612,7 +747,8 @@ extern "C" int nsgp_plan_create(nsgp_plan_t** out, const nsgp_tensor_t* tensors,
     P->n_layers = (int)ld.size();
     P->n_chunks = (int)cd.size();
     P->n_tiles_fast = (int)fast_tiles.size();
-    P->split_kind = (all_split && !fast_tiles.empty()) ? split_kind : 0;
+    P->n_tiles_v2 = (int)v2_tiles.size();
+    P->split_kind = (all_split && !(fast_tiles.empty() && v2_tiles.empty())) ? split_kind : 0;
     P->n_tiles_generic = (int)gen_tiles.size();
     P->gemm_flops = flops;
     P->bytes = bytes;
@@ -639,6 +775,7 @@ extern "C" int nsgp_plan_create(nsgp_plan_t** out, const nsgp_tensor_t* tensors,
     all_tiles.insert(all_tiles.end(), gen_tiles.begin(), gen_tiles.end());
     all_tiles.insert(all_tiles.end(), lr1.begin(), lr1.end());
     all_tiles.insert(all_tiles.end(), lr2.begin(), lr2.end());
+    all_tiles.insert(all_tiles.end(), v2_tiles.begin(), v2_tiles.end());
     P->n_tiles_lr1 = (int)lr1.size();
     P->n_tiles_lr2 = (int)lr2.size();
     P->n_chunks_lr = (int)lr_chunks.size();
@@ -656,7 +793,6 @@ extern "C" int nsgp_plan_create(nsgp_plan_t** out, const nsgp_tensor_t* tensors,
     } while (0)
     PLAN_HIP(hipMalloc(&P->d_tensors, sizeof(TensorDev) * td.size()));
     PLAN_HIP(hipMemcpy(P->d_tensors, td.data(), sizeof(TensorDev) * td.size(), hipMemcpyHostToDevice));
-    if (P->split_kind == 2) PLAN_HIP(hipMalloc(&P->d_amax, sizeof(unsigned) * NSLOT * (size_t)n));
     PLAN_HIP(hipMalloc(&P->d_chunks, sizeof(ChunkDev) * cd.size()));
     PLAN_HIP(hipMemcpy(P->d_chunks, cd.data(), sizeof(ChunkDev) * cd.size(), hipMemcpyHostToDevice));
     if (!lr_chunks.empty()) {
@@ -681,7 +817,7 @@ extern "C" int nsgp_plan_create(nsgp_plan_t** out, const nsgp_tensor_t* tensors,
         (rc = enable_big_lds(nsgp_project_kernel<NSGP_OPT_SGD, true>)) || (rc = enable_big_lds(nsgp_project_kernel<NSGP_OPT_SGD, false>)) ||
         (rc = enable_big_lds(nsgp_project_kernel<NSGP_OPT_ADAM, true>)) || (rc = enable_big_lds(nsgp_project_kernel<NSGP_OPT_ADAM, false>)) ||
         (rc = enable_big_lds(nsgp_project_kernel<NSGP_OPT_SGD, true, 1>)) || (rc = enable_big_lds(nsgp_project_kernel<NSGP_OPT_ADAM, true, 1>)) ||
-        (rc = enable_big_lds(nsgp_project_kernel<NSGP_OPT_SGD, true, 2>)) || (rc = enable_big_lds(nsgp_project_kernel<NSGP_OPT_ADAM, true, 2>))) {
+        (rc = enable_v2_lds(nsgp_project_v2_kernel<NSGP_OPT_SGD>)) || (rc = enable_v2_lds(nsgp_project_v2_kernel<NSGP_OPT_ADAM>))) {
         nsgp_plan_destroy(P);
         return rc;
     }
@@ -704,7 +840,6 @@ extern "C" int nsgp_plan_destroy(nsgp_plan_t* P) {
         if (P->d_dyn[s]) keep(hipFree(P->d_dyn[s]), "hipFree(dyn)");
     }
     for (hipEvent_t e : P->prof_ev) keep(hipEventDestroy(e), "hipEventDestroy(profile)");
-    if (P->d_amax) keep(hipFree(P->d_amax), "hipFree(amax)");
     if (P->d_tensors) keep(hipFree(P->d_tensors), "hipFree(tensors)");
     if (P->d_layers) keep(hipFree(P->d_layers), "hipFree(layers)");
     if (P->d_tiles) keep(hipFree(P->d_tiles), "hipFree(tiles)");
@@ -719,7 +854,7 @@ extern "C" int nsgp_plan_stats(const nsgp_plan_t* P, double* gemm_flops, double*
     if (!P) return fail(NSGP_ERR_INVALID, "nsgp_plan_stats: null plan");
     if (gemm_flops) *gemm_flops = P->gemm_flops;  // the dense form's 2*Cout*D^2 for every projected layer
     if (bytes) *bytes = P->bytes;
-    if (n_tiles) *n_tiles = P->n_tiles_fast + P->n_tiles_generic;
+    if (n_tiles) *n_tiles = P->n_tiles_fast + P->n_tiles_generic + P->n_tiles_v2;
     if (n_proj) *n_proj = P->n_layers;
     return NSGP_OK;
 }
@@ -735,13 +870,25 @@ extern "C" int nsgp_plan_lowrank_stats(const nsgp_plan_t* P, int* n_lowrank, dou
 
 extern "C" int nsgp_plan_uses_split_mfma(const nsgp_plan_t* P) { return P ? P->split_kind : 0; }
 
-extern "C" size_t nsgp_split_projector_f16_bytes(int D) { return D > 0 ? (size_t)D * D * 4 : 0; }
+extern "C" int nsgp_plan_tile_counts(const nsgp_plan_t* P, int* fast_128, int* generic_128, int* split_f16_256) {
+    if (!P) return fail(NSGP_ERR_INVALID, "nsgp_plan_tile_counts: null plan");
+    if (fast_128) *fast_128 = P->n_tiles_fast;
+    if (generic_128) *generic_128 = P->n_tiles_generic;
+    if (split_f16_256) *split_f16_256 = P->n_tiles_v2;
+    return NSGP_OK;
+}
 
-extern "C" int nsgp_split_projector_f16(const float* proj, int D, float scale, void* out, void* stream_) {
-    if (!proj || !out || D <= 0 || D % 8 != 0 || !(scale > 0.0f)) return fail(NSGP_ERR_INVALID, "nsgp_split_projector_f16: bad argument");
+// [pre-tiled two-term split of diag(cscale) P^T: D*D*4 B][cscale: D floats][1 / cscale: D floats]
+extern "C" size_t nsgp_split_projector_f16_bytes(int D) { return D > 0 ? v2_operand_bytes(D, D) + 2 * (size_t)D * 4 : 0; }
+
+extern "C" int nsgp_split_projector_f16(const float* proj, int D, void* out, void* stream_) {
+    if (!proj || !out || D <= 0 || D % 64 != 0) return fail(NSGP_ERR_INVALID, "nsgp_split_projector_f16: bad argument (D must be a multiple of 64)");
     if (!aligned16(out)) return fail(NSGP_ERR_INVALID, "nsgp_split_projector_f16: output must be 16-byte aligned");
-    hipLaunchKernelGGL(nsgp_split_transpose_f16x2_kernel, dim3((D + 31) / 32, (D + 31) / 32), dim3(256), 0, static_cast<hipStream_t>(stream_),
-                       proj, D, D, scale, static_cast<_Float16*>(out));
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    float* cscale = reinterpret_cast<float*>(static_cast<char*>(out) + v2_operand_bytes(D, D));
+    hipLaunchKernelGGL(nsgp_col_scales_f16x2_kernel, dim3((D + 31) / 32), dim3(256), 0, stream, proj, D, D, cscale, cscale + D);
+    NSGP_LAUNCH_CHECK();
+    hipLaunchKernelGGL(nsgp_split_transpose_f16x2_v2_kernel, dim3((D + 31) / 32, (D + 31) / 32), dim3(256), 0, stream, proj, D, D, cscale, out);
     NSGP_LAUNCH_CHECK();
     return NSGP_OK;
 }
@@ -777,25 +924,26 @@ extern "C" int nsgp_plan_step(nsgp_plan_t* P, float* const* grads, const nsgp_hy
     const bool prof = P->prof_n < P->prof_cap;
     if (prof) NSGP_HIP(hipEventRecord(P->prof_ev[3 * P->prof_n + 0], stream));
 
-    unsigned* amax = P->d_amax ? P->d_amax + (size_t)s * P->n_tensors : nullptr;
-    if (amax) NSGP_HIP(hipMemsetAsync(amax, 0, sizeof(unsigned) * (size_t)P->n_tensors, stream));
     if (P->optimizer == NSGP_OPT_SGD)
-        hipLaunchKernelGGL(nsgp_update_kernel<NSGP_OPT_SGD>, dim3(P->n_chunks), dim3(256), 0, stream, P->d_chunks, P->d_tensors, d, amax);
+        hipLaunchKernelGGL(nsgp_update_kernel<NSGP_OPT_SGD>, dim3(P->n_chunks), dim3(256), 0, stream, P->d_chunks, P->d_tensors, d);
     else
-        hipLaunchKernelGGL(nsgp_update_kernel<NSGP_OPT_ADAM>, dim3(P->n_chunks), dim3(256), 0, stream, P->d_chunks, P->d_tensors, d, amax);
+        hipLaunchKernelGGL(nsgp_update_kernel<NSGP_OPT_ADAM>, dim3(P->n_chunks), dim3(256), 0, stream, P->d_chunks, P->d_tensors, d);
     NSGP_LAUNCH_CHECK();
     if (prof) NSGP_HIP(hipEventRecord(P->prof_ev[3 * P->prof_n + 1], stream));
+    if (P->n_tiles_v2 > 0) {
+        const TileDev* vt = P->d_tiles + P->n_tiles_fast + P->n_tiles_generic + P->n_tiles_lr1 + P->n_tiles_lr2;
+        if (P->optimizer == NSGP_OPT_SGD)
+            hipLaunchKernelGGL(nsgp_project_v2_kernel<NSGP_OPT_SGD>, dim3(P->n_tiles_v2), dim3(V2_THREADS), V2_SMEM_BYTES, stream, vt, P->d_layers, d);
+        else
+            hipLaunchKernelGGL(nsgp_project_v2_kernel<NSGP_OPT_ADAM>, dim3(P->n_tiles_v2), dim3(V2_THREADS), V2_SMEM_BYTES, stream, vt, P->d_layers, d);
+        NSGP_LAUNCH_CHECK();
+    }
     if (P->n_tiles_fast > 0) {
-        if (P->split_kind == 2) {
+        if (P->split_kind == 1) {
             if (P->optimizer == NSGP_OPT_SGD)
-                hipLaunchKernelGGL((nsgp_project_kernel<NSGP_OPT_SGD, true, 2>), dim3(P->n_tiles_fast), dim3(THREADS), F2_SMEM_BYTES, stream, P->d_tiles, P->d_layers, d, amax);
+                hipLaunchKernelGGL((nsgp_project_kernel<NSGP_OPT_SGD, true, 1>), dim3(P->n_tiles_fast), dim3(THREADS), X3_SMEM_BYTES, stream, P->d_tiles, P->d_layers, d);
             else
-                hipLaunchKernelGGL((nsgp_project_kernel<NSGP_OPT_ADAM, true, 2>), dim3(P->n_tiles_fast), dim3(THREADS), F2_SMEM_BYTES, stream, P->d_tiles, P->d_layers, d, amax);
-        } else if (P->split_kind == 1) {
-            if (P->optimizer == NSGP_OPT_SGD)
-                hipLaunchKernelGGL((nsgp_project_kernel<NSGP_OPT_SGD, true, 1>), dim3(P->n_tiles_fast), dim3(THREADS), X3_SMEM_BYTES, stream, P->d_tiles, P->d_layers, d, amax);
-            else
-                hipLaunchKernelGGL((nsgp_project_kernel<NSGP_OPT_ADAM, true, 1>), dim3(P->n_tiles_fast), dim3(THREADS), X3_SMEM_BYTES, stream, P->d_tiles, P->d_layers, d, amax);
+                hipLaunchKernelGGL((nsgp_project_kernel<NSGP_OPT_ADAM, true, 1>), dim3(P->n_tiles_fast), dim3(THREADS), X3_SMEM_BYTES, stream, P->d_tiles, P->d_layers, d);
         } else if (P->optimizer == NSGP_OPT_SGD)
             hipLaunchKernelGGL((nsgp_project_kernel<NSGP_OPT_SGD, true>), dim3(P->n_tiles_fast), dim3(THREADS), SMEM_BYTES, stream, P->d_tiles, P->d_layers, d);
         else

@@ -60,23 +60,28 @@ def split_projector(P: torch.Tensor) -> torch.Tensor:
     return out
 
 
-def split_projector_f16(P: torch.Tensor):
-    """Two-term fp16 split of ``scale * P^T`` (layout [n][k/8][term][8], 4 bytes per element of P) and the power-of-two
-    ``scale`` that puts the largest |entry| of P into [2^13, 2^14) -- fp16 overflows at 65504.  One launch per projector per
-    task (plus one ``abs().max()`` to find the scale)."""
-    import math
+def split_projector_f16(P: torch.Tensor) -> torch.Tensor:
+    """Pre-tiled two-term fp16 split of ``diag(c) P^T`` with one power-of-two scale ``c[n]`` per projector column (largest
+    |entry| of the column into [2^13, 2^14); fp16 overflows at 65504), as one uint8 buffer:
+    ``[n/64][k/8][term][n%64][8 fp16]`` (4 bytes per element of P), then ``c`` and ``1/c`` as fp32 ``[D]`` each.  Two launches
+    per projector per task; ``unpack_split_f16`` turns the buffer back into tensors for inspection."""
     lib = _lib.load_library()
     D = P.shape[0]
     if P.shape != (D, D):
         raise ValueError("projector must be square")
-    m = float(P.abs().max().item())
-    if not math.isfinite(m):
-        raise ValueError("projector has non-finite entries")
-    scale = 1.0 if m == 0.0 else 2.0 ** (14 - math.frexp(m)[1])       # m = f * 2^e, f in [0.5, 1)  ->  m * scale in [2^13, 2^14)
-    scale = min(max(scale, 2.0 ** -100), 2.0 ** 100)
-    out = torch.empty(lib.nsgp_split_projector_f16_bytes(D) // 2, dtype=torch.float16, device=P.device)
-    _lib.check(lib.nsgp_split_projector_f16(_dev(P, "P"), D, scale, C.c_void_p(out.data_ptr()), _stream()), "nsgp_split_projector_f16")
-    return out, scale
+    if D % 64 != 0:
+        raise ValueError("the fp16 split needs D to be a multiple of 64")
+    out = torch.empty(lib.nsgp_split_projector_f16_bytes(D), dtype=torch.uint8, device=P.device)
+    _lib.check(lib.nsgp_split_projector_f16(_dev(P, "P"), D, C.c_void_p(out.data_ptr()), _stream()), "nsgp_split_projector_f16")
+    return out
+
+
+def unpack_split_f16(buf: torch.Tensor, D: int):
+    """(terms [2 x D x D] fp16 as [term][n][k], c [D], 1/c [D]) from the buffer ``split_projector_f16`` returns."""
+    planes = buf[:D * D * 4].view(torch.float16).view(D // 64, D // 8, 2, 64, 8)       # [n/64][k/8][term][n%64][8]
+    terms = planes.permute(2, 0, 3, 1, 4).reshape(2, D, D)
+    scales = buf[D * D * 4:].view(torch.float32)
+    return terms, scales[:D], scales[D:2 * D]
 
 
 def build_projector(V: torch.Tensor, first_col: int, normalise: bool, out: torch.Tensor = None,

@@ -310,7 +310,7 @@ class NSCLOptimizerBase(Optimizer):
         also keeps its address from being recycled while the copy is alive)."""
         c = self._splits.get(name)
         if c is None or c["P"] is not P or c["version"] != P._version or c["kind"] != kind:
-            split, scale = (ops.split_projector(P), 1.0) if kind == 1 else ops.split_projector_f16(P)
+            split, scale = (ops.split_projector(P) if kind == 1 else ops.split_projector_f16(P)), 0.0
             c = self._splits[name] = dict(P=P, version=P._version, kind=kind, split=split, scale=scale)
         return c["split"], c["scale"]
 
@@ -328,6 +328,16 @@ class NSCLOptimizerBase(Optimizer):
             f, b, t, n = C.c_double(), C.c_double(), C.c_int(), C.c_int()
             _lib.check(lib.nsgp_plan_stats(plan["handle"], C.byref(f), C.byref(b), C.byref(t), C.byref(n)))
             tot = [tot[0] + f.value, tot[1] + b.value, tot[2] + t.value, tot[3] + n.value]
+        return tuple(tot)
+
+    def tile_counts(self):
+        """(fast 128x128 tiles, guarded 128x128 tiles, fp16-split 256x128 tiles) of the dense projection, over the current plans."""
+        lib = _lib.load_library()
+        tot = [0, 0, 0]
+        for plan in self._plans:
+            a, b, c = C.c_int(), C.c_int(), C.c_int()
+            _lib.check(lib.nsgp_plan_tile_counts(plan["handle"], C.byref(a), C.byref(b), C.byref(c)))
+            tot = [tot[0] + a.value, tot[1] + b.value, tot[2] + c.value]
         return tuple(tot)
 
     def lowrank_stats(self):

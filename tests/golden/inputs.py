@@ -70,6 +70,57 @@ def g1_covariances():
     return out
 
 
+# ------------------------------------------------------------------ G1b: 128-aligned layers
+# Shapes the MFMA fast tiles and the split kernels take (rows % 128 == 0, D % 128 == 0) -- G1's layers all have Cout <= 32 and
+# run the guarded generic tile.  The projected parameters start at ZERO, so after the first step they ARE the projected
+# update (0 + u is exact, and weight decay adds nothing): the fixture pins the reference's `torch.mm(update, P)` itself, row by
+# row, with no ulp(p) in the way.  The gradient rows span six decades: a per-row check then means something.
+G1B_STEPS = 2
+G1B_KINDS = ("sgd", "adamw")
+_G1B = [
+    ("neck.lateral_convs.1.conv.weight", (128, 128, 1, 1), True),
+    ("backbone.layer3.0.conv1.weight", (256, 256, 1, 1), True),
+    ("neck.fc.weight", (128, 256), True),
+    ("backbone.layer3.0.bn1.weight", (256,), False),
+]
+
+
+def g1b_layers():
+    return [n for n, _, _ in _G1B], [s for _, s, _ in _G1B]
+
+
+def g1b_projected():
+    return [n for n, _, p in _G1B if p]
+
+
+def g1b_params():
+    out = []
+    for i, (_, shp, proj) in enumerate(_G1B):
+        rng = np.random.default_rng(150 + i)
+        out.append(np.zeros(shp, np.float32) if proj else (rng.standard_normal(shp) * 0.02).astype(np.float32))
+    return out
+
+
+def g1b_grads(step):
+    out = []
+    for i, (_, shp, proj) in enumerate(_G1B):
+        rng = np.random.default_rng(1500 + 37 * step + i)
+        g = rng.standard_normal(shp).astype(np.float32)
+        if proj:    # row r scaled by 10^(-6 (r mod 32) / 31)
+            rows = np.power(10.0, -6.0 * (np.arange(shp[0]) % 32) / 31.0).astype(np.float32)
+            g *= rows.reshape((-1,) + (1,) * (len(shp) - 1))
+        out.append(g)
+    return out
+
+
+def g1b_covariances():
+    out = {}
+    for i, (n, shp, proj) in enumerate(_G1B):
+        if proj:
+            out[n] = covariance_like(int(np.prod(shp[1:])), 2500 + i, rows_mult=2)
+    return out
+
+
 # ------------------------------------------------------------------ G2
 G2_OFFSETS = [0.0, 0.3, -0.3, 2.0, 1.0, -1.0, -5.0]
 

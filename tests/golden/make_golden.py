@@ -79,6 +79,42 @@ def run_optimizer(kind):
     save(f"g1_{kind}.npz", **out)
 
 
+def run_optimizer_aligned(kind):
+    """G1b: the same reference classes on 128-aligned layers (see inputs.py); P only with 'sgd' (AdamW shares its rule)."""
+    names, shapes = I.g1b_layers()
+    params = [nn.Parameter(torch.from_numpy(a)) for a in I.g1b_params()]
+    fea_in = {n: torch.from_numpy(c) for n, c in I.g1b_covariances().items()}
+    cls = dict(sgd=ref_sgd.SGDNSCL, adamw=ref_adamw.AdamWNSCL)[kind]
+    opt = cls(params, svd=True, **I.G1_HYPER[kind])
+    opt.param_groups[0]["names"] = list(names)
+    opt.get_eigens(fea_in)
+    opt.get_transforms(offset=I.G1_OFFSET)
+    out = {}
+    for n in names:
+        if n in opt.transforms:
+            key = n.replace(".", "_")
+            out[f"sigma__{key}"] = opt.eigens[n]["eigen_value"].numpy()
+            if kind == "sgd":
+                out[f"P__{key}"] = opt.transforms[n].numpy()
+            else:
+                out[f"Pnorm__{key}"] = opt.transforms[n].norm().numpy()
+    for step in range(I.G1B_STEPS):
+        for p, g in zip(params, I.g1b_grads(step)):
+            p.grad = torch.from_numpy(g)
+        opt.step()
+        for n, p in zip(names, params):
+            key = n.replace(".", "_")
+            out[f"p_step{step}__{key}"] = p.detach().numpy().copy()
+            if step == 0:
+                out[f"g_step{step}__{key}"] = p.grad.numpy().copy()
+    for n, p in zip(names, params):
+        key = n.replace(".", "_")
+        for sk in ("previous_grad", "exp_avg", "exp_avg_sq"):
+            if sk in opt.state[p]:
+                out[f"{sk}__{key}"] = opt.state[p][sk].numpy().copy()
+    save(f"g1b_{kind}.npz", **out)
+
+
 # ---------------------------------------------------------------- G2 thresholds
 def run_thresholds():
     spectra = I.g2_spectra()
@@ -286,8 +322,14 @@ def run_task_split():
 
 
 if __name__ == "__main__":
+    if sys.argv[1:] == ["g1b"]:        # only the 128-aligned optimizer fixtures
+        for kind in I.G1B_KINDS:
+            run_optimizer_aligned(kind)
+        sys.exit(0)
     for kind in ("sgd", "sgd_nesterov", "adamw", "adamw_amsgrad", "adam", "sgdna"):
         run_optimizer(kind)
+    for kind in I.G1B_KINDS:
+        run_optimizer_aligned(kind)
     run_thresholds()
     run_covariance()
     run_prototypes()

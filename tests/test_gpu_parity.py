@@ -1,10 +1,17 @@
 """GPU parity tests: the HIP path (through the C ABI) against the CPU oracle and the golden
 vectors produced by the reference.  Run on the GPU box with ``pytest -m gpu``.
 
-Tolerances (north_star): fp32 projected gradients within 1e-5 relative -- measured as
-max|ours - ref| <= 1e-5 * max|ref| per tensor (an elementwise relative bound is meaningless on
-entries that cancel to ~0; the reference's own fp32 GEMM does not meet one against fp64 either);
-integer / bool results (ranks, masks, prototype indices, counts) bit-exact.
+THE GATE (north_star: "fp32 projected gradients within 1e-5 rel"), stated once and used by every projection test here:
+
+    for every projected update and EVERY OUTPUT ROW m:   max_n |ours[m,n] - ref[m,n]|  <=  1e-5 * max_n |ref[m,n]|
+
+(``_row_rel``; a row = one output channel of a conv / one output feature of a linear = one row of the reference's
+``torch.mm(update.view(Cout, -1), P)``, SGD_NSCL.py:85-90).  Per row, not per tensor: the reference's fp32 mm keeps fp32
+relative accuracy in every row however small that row is next to the others, and so must every MFMA path of the product.
+An ELEMENTWISE relative bound is not meaningful (entries that cancel to ~0; the reference's own GEMM does not meet one against
+fp64).  Where a test can only see ``p`` after ``p += update`` with p != 0, the fp32 rounding of that add (ulp(p)) is allowed on
+top and the test says so; the tests that pin the gate itself start from p = 0, where the add is exact.
+Integer / bool results (ranks, masks, prototype indices, counts) are bit-exact.
 """
 import os
 
@@ -24,6 +31,16 @@ def _rel(a, b):
     a = a.detach().cpu().double() if isinstance(a, torch.Tensor) else torch.as_tensor(a).double()
     b = b.detach().cpu().double() if isinstance(b, torch.Tensor) else torch.as_tensor(b).double()
     return ((a - b).abs().max() / b.abs().max().clamp_min(1e-30)).item()
+
+
+def _row_rel(a, b):
+    """The gate's left-hand side: max over rows (dim 0) of max_n|a - b| / max_n|b|; rows where b is all zero must match exactly."""
+    a = (a.detach() if isinstance(a, torch.Tensor) else torch.as_tensor(a)).double()
+    b = (b.detach() if isinstance(b, torch.Tensor) else torch.as_tensor(b)).double().to(a.device)
+    a, b = a.reshape(a.shape[0], -1), b.reshape(b.shape[0], -1)
+    err, mag = (a - b).abs().amax(1), b.abs().amax(1)
+    assert bool((err[mag == 0] == 0).all()), "a row the reference leaves at zero is not zero"
+    return (err[mag > 0] / mag[mag > 0]).max().item() if bool((mag > 0).any()) else 0.0
 
 
 @pytest.fixture(scope="module")
@@ -121,6 +138,48 @@ def test_g1_steps_with_golden_projectors(N, dev, golden_dir, kind):
         for sk in ("previous_grad", "exp_avg", "exp_avg_sq", "max_exp_avg_sq"):
             if sk in st:
                 assert _rel(st[sk], g[f"{sk}__{_key(n)}"]) <= 1e-6, (kind, n, sk)
+
+
+@pytest.mark.parametrize("split", [False, "bf16x3", "f16x2"])
+@pytest.mark.parametrize("kind", list(I.G1B_KINDS))
+def test_g1b_aligned_goldens_per_row(N, dev, golden_dir, kind, split):
+    """The reference's own output on 128-aligned layers (G1b) against the kernels the bench times: the whole-tile fp32-MFMA
+    kernel, the three-term bf16 split and the two-term fp16 split (256 x 128 LDS-DMA tiles).  Parameters start at zero, so the
+    first step's result IS the projected update and the gate is checked row by row with nothing added; gradient rows span six
+    decades, so a path that is only accurate relative to the tensor's largest entry fails here."""
+    g = np.load(os.path.join(golden_dir, f"g1b_{kind}.npz"))
+    gP = np.load(os.path.join(golden_dir, "g1b_sgd.npz"))
+    names, _ = I.g1b_layers()
+    params = [torch.nn.Parameter(torch.from_numpy(a).to(dev)) for a in I.g1b_params()]
+    opt = _make_opt(N, kind, params)
+    opt.param_groups[0]["names"] = list(names)
+    opt.split_mfma = split
+    for n in I.g1b_projected():
+        opt.transforms[n] = torch.from_numpy(gP[f"P__{_key(n)}"]).to(dev)
+    prev = [torch.from_numpy(a) for a in I.g1b_params()]
+    for step in range(I.G1B_STEPS):
+        for p, a in zip(params, I.g1b_grads(step)):
+            p.grad = torch.from_numpy(a).to(dev)
+        opt.step()
+        torch.cuda.synchronize()
+        fast, generic, v2 = opt.tile_counts()
+        assert generic == 0 and ((v2 > 0 and fast == 0) if split == "f16x2" else (fast > 0 and v2 == 0)), (fast, generic, v2)
+        assert opt.uses_split_mfma() == split
+        for n, p, p0 in zip(names, params, prev):
+            ref = torch.from_numpy(g[f"p_step{step}__{_key(n)}"])
+            if step == 0 and n in opt.transforms:
+                assert _row_rel(p, ref) <= REL, (kind, split, n, _row_rel(p, ref))            # THE GATE, nothing added
+            upd_ref = ref.double() - p0.double()
+            upd = p.detach().cpu().double() - p0.double()
+            allowed = REL * upd_ref.abs().max().item() + 2 * 2.0 ** -23 * ref.abs().max().item()
+            assert (upd - upd_ref).abs().max().item() <= allowed, (kind, split, n, step)
+            if step == 0:
+                assert _rel(p.grad, g[f"g_step0__{_key(n)}"]) <= 1e-6, (kind, n, "grad mutation")
+        prev = [torch.from_numpy(g[f"p_step{step}__{_key(n)}"]) for n in names]
+    for n, p in zip(names, params):
+        for sk in ("previous_grad", "exp_avg", "exp_avg_sq"):
+            if sk in opt.state[p]:
+                assert _rel(opt.state[p][sk], g[f"{sk}__{_key(n)}"]) <= 1e-6, (kind, n, sk)
 
 
 @pytest.mark.parametrize("kind", ["sgd", "adam"])
@@ -263,7 +322,7 @@ def test_sim_counts_vs_oracle_ragged(N, dev):
         assert torch.equal(got, got.t())
 
 
-# ------------------------------------------------------------------ full-size properties (no oracle at this size)
+# ------------------------------------------------------------------ full-size properties
 def test_full_size_step_properties(N, dev):
     """R-50-FPN layer shapes: (i) with P = I the projected step equals the un-projected one
     bit for bit; (ii) with a true projector, projecting twice equals projecting once
@@ -282,47 +341,98 @@ def test_full_size_step_properties(N, dev):
     b = torch.randn(rows, cols, generator=g).to(dev)
     lin = ops.project(a + b, P)
     assert _rel(lin, once + ops.project(b, P)) <= 1e-5
-    ref = a @ P  # rocBLAS fp32 on the same device (not the oracle; a cross-check at full size)
-    assert _rel(once, ref) <= 1e-5
+    ref = O.project_update(a.cpu(), P.cpu())        # the oracle (torch-CPU fp32 mm, the reference's arithmetic) at full size
+    assert _row_rel(once, ref) <= REL
+
+
+def _table_projectors(dev, layers):
+    """One projector per (D, Frobenius-normalised?) pair of the table, built the way the product builds them in a run
+    (C = X^T X, X = [4D x D] ~ N(0,1) diag(logspace(0,-3,D)); eigh -> elbow -> HIP projector kernel) and shared by
+    the layers of that shape.  The step kernels are judged GIVEN P, so the oracle gets a CPU copy of the same matrices."""
+    from nsgp_repre_amd import ops
+    from nsgp_repre_amd.optim.threshold import elbow_index
+    cache = {}
+    for n, cout, D in layers:
+        key = (D, "backbone" in n)
+        if key in cache:
+            continue
+        gen = torch.Generator(device=dev).manual_seed(2000 + D)
+        X = torch.randn(4 * D, D, device=dev, generator=gen) * torch.logspace(0, -3, D, device=dev)[None, :]
+        lam, Q = torch.linalg.eigh((X.t() @ X).contiguous())
+        sv = lam.abs()
+        order = torch.argsort(sv, descending=True, stable=True)
+        first = elbow_index(sv[order].cpu().numpy(), 0.0, "sgd")
+        cache[key] = ops.build_projector(Q[:, order].contiguous(), int(first), key[1])
+        del X, lam, Q
+    return cache
 
 
 @pytest.mark.parametrize("split", [False, "bf16x3", "f16x2"])
-def test_full_r50_table_one_step_vs_torch_gpu(N, dev, split):
-    """The complete 50-layer R-50-FPN table (BASELINE configs[1]) in one plan: every
-    projected parameter must equal p - lr*(buf @ P) computed layer by layer with torch on the
-    GPU; un-projected tensors plain SGD.  Both MFMA paths: fp32 and the three-term bf16 split."""
-    layers = O.resnet_fpn_projected_layers(50)
-    gen = torch.Generator(device="cpu").manual_seed(7)
-    params, names, Ps = [], [], {}
-    for i, (n, cout, D) in enumerate(layers):
-        k = 3 if D % 9 == 0 and "conv2" in n or "fpn_convs" in n else 1
-        cin = D // (k * k)
-        params.append(torch.nn.Parameter((torch.randn(cout, cin, k, k, generator=gen) * 0.02).to(dev)))
+@pytest.mark.parametrize("depth", [50, 101])
+def test_full_table_one_step_vs_oracle_per_row(N, dev, depth, split):
+    """The complete projected-layer table of R-50-FPN (BASELINE configs[1]: 50 layers, 118.3 GFLOP) and R-101-FPN (configs[4]:
+    101 layers, 175.9 GFLOP) in one plan, one SGDNSCL step, every MFMA path, against the ORACLE run over the same table on the
+    CPU -- row by row under THE GATE.  Projected parameters start at zero (the step's result is the projected update itself);
+    gradient rows span three decades.  With NSGP_REPORT_DIR set, the measured errors of every layer -- against the oracle and,
+    for both, against an fp64 product -- are written there (profiles/r02/parity_*.json come from this test)."""
+    import json
+    layers = O.resnet_fpn_projected_layers(depth)
+    Pc = _table_projectors(dev, layers)
+    gen = torch.Generator(device="cpu").manual_seed(7 + depth)
+    params, names, shapes, Ps = [], [], {}, {}
+    for n, cout, D in layers:
+        k = 3 if ("conv2" in n or "fpn_convs" in n) else 1
+        shapes[n] = (cout, D // (k * k), k, k)
+        params.append(torch.nn.Parameter(torch.zeros(shapes[n], device=dev)))
         names.append(n)
-        Ps[n] = (torch.randn(D, D, generator=gen) / D ** 0.5).to(dev)
+        Ps[n] = Pc[(D, "backbone" in n)]
     params.append(torch.nn.Parameter(torch.randn(1000, generator=gen).to(dev)))
     names.append("backbone.bn.weight")
-    opt = N.SGDNSCL(params, lr=0.02, momentum=0.9, weight_decay=1e-4, svd=True)
+    hp = dict(lr=0.02, momentum=0.9, weight_decay=1e-4)
+    opt = N.SGDNSCL(params, svd=True, **hp)
     opt.param_groups[0]["names"] = names
-    for n, P in Ps.items():
-        opt.transforms[n] = P
+    opt.transforms.update(Ps)
     opt.split_mfma = split
-    before = [p.detach().clone() for p in params]
-    grads = [torch.randn(p.shape, generator=gen).to(dev) for p in params]
+    grads = []
+    for n, p in zip(names, params):
+        gr = torch.randn(p.shape, generator=gen) * 1e-3
+        if n in Ps:
+            gr *= torch.pow(10.0, -3.0 * (torch.arange(p.shape[0]) % 16) / 15.0).view(-1, 1, 1, 1)
+        grads.append(gr)
+    cpu_params = [p.detach().cpu().clone() for p in params]
     for p, gr in zip(params, grads):
-        p.grad = gr.clone()
+        p.grad = gr.clone().to(dev)
     opt.step()
     torch.cuda.synchronize()
     flops, nbytes, ntiles, nproj = opt.plan_stats()
-    assert nproj == 50 and abs(flops / 1e9 - 118.3) < 0.05 and ntiles == 1622
-    assert opt.uses_split_mfma() == split
-    for n, p, p0, gr in zip(names, params, before, grads):
-        d = gr + 1e-4 * p0
-        upd = -(0.02 * d)
-        if n in Ps:
-            upd = (upd.view(upd.shape[0], -1) @ Ps[n]).view_as(upd)
-        exp = p0 + upd
-        assert _rel(p - p0, exp - p0) <= 2e-5, n
+    fast, generic, v2 = opt.tile_counts()
+    want_gf = {50: 118.3, 101: 175.9}[depth]
+    assert nproj == len(layers) and abs(flops / 1e9 - want_gf) < 0.06 and generic == 0
+    assert opt.uses_split_mfma() == split and ((v2 == {50: 836, 101: 1414}[depth] and fast == 0) if split == "f16x2" else (fast == {50: 1622, 101: 2778}[depth] and v2 == 0))
+    tr_cpu = {k: v.cpu() for k, v in Pc.items()}
+    O.sgd_nscl_step(names, cpu_params, [g.clone() for g in grads], [dict() for _ in names],
+                    {n: tr_cpu[(shapes[n][1] * shapes[n][2] * shapes[n][3], "backbone" in n)] for n in Ps}, **hp)
+    report, worst = [], 0.0
+    for n, p, q, gr in zip(names, params, cpu_params, grads):
+        if n not in Ps:
+            assert _rel(p, q) <= 1e-6, n
+            continue
+        vs_oracle = _row_rel(p, q)
+        worst = max(worst, vs_oracle)
+        u64 = (-(0.02 * gr.to(dev))).double().view(gr.shape[0], -1) @ Ps[n].double()      # p0 = 0: weight decay adds nothing, buf = g
+        rec = dict(layer=n, rows=gr.shape[0], D=Ps[n].shape[0], vs_oracle_row_rel=vs_oracle,
+                   vs_fp64_row_rel=_row_rel(p, u64), vs_fp64_tensor_rel=_rel(p.detach().view(gr.shape[0], -1), u64),
+                   oracle_vs_fp64_row_rel=_row_rel(q.to(dev), u64))
+        report.append(rec)
+        assert vs_oracle <= REL, rec
+    out_dir = os.environ.get("NSGP_REPORT_DIR")
+    if out_dir:
+        os.makedirs(out_dir, exist_ok=True)
+        summary = dict(table=f"R-{depth}-FPN", path=split or "f32", gate="max_n|ours-ref| <= 1e-5 * max_n|ref| per output row",
+                       worst_row_rel_vs_oracle=worst, worst_row_rel_vs_fp64=max(r["vs_fp64_row_rel"] for r in report),
+                       worst_tensor_rel_vs_fp64=max(r["vs_fp64_tensor_rel"] for r in report),
+                       oracle_worst_row_rel_vs_fp64=max(r["oracle_vs_fp64_row_rel"] for r in report), layers=report)
+        json.dump(summary, open(os.path.join(out_dir, f"parity_r{depth}_{split or 'f32'}.json"), "w"), indent=1)
 
 
 # ------------------------------------------------------------------ low-rank form (opt-in)
@@ -514,7 +624,8 @@ def test_split_mfma_steps_vs_oracle(N, dev, kind, split):
 
 @pytest.mark.parametrize("split", ["bf16x3", "f16x2"])
 def test_split_mfma_with_misaligned_gradients_and_projector_edits(N, dev, split):
-    """(i) gradient views at odd offsets: the split kernel's tile falls back to the guarded fp32 loader for that operand;
+    """(i) gradient views at odd offsets: the bf16 kernel's tile falls back to the guarded fp32 loader for that operand, the
+    fp16 path reads them with scalar loads in the elementwise launch that writes the split copy;
     (ii) an in-place edit of a projector invalidates its cached split (tensor version in the plan key)."""
     shapes = {"backbone.a.weight": (128, 256), "neck.c.weight": (256, 128, 3, 3)}
     names = list(shapes)
@@ -535,18 +646,22 @@ def test_split_mfma_with_misaligned_gradients_and_projector_edits(N, dev, split)
 
 
 def test_f16x2_split_survives_a_wide_dynamic_range(N, dev):
-    """fp16 has a 5-bit exponent: the two-term path scales each operand matrix by one power of two.  Updates 1e+4 and 1e-6
-    times the usual size, rows of the update 1e-6 times smaller than the rest, a projector with tiny entries and an all-zero
-    gradient must all stay inside the gate (relative to the tensor's largest update) -- and no inf / nan may appear."""
+    """fp16 has a 5-bit exponent: the two-term path scales every ROW of the update and every COLUMN of the projector by its own
+    power of two.  Updates 1e+4 and 1e-6 times the usual size, rows 1e-6 times smaller than their neighbours, projector columns
+    over six decades, a tiny projector and an all-zero gradient: every output row must meet THE GATE against ITS OWN maximum
+    (round 1 judged the small rows against the large rows' maximum and could not see a per-tensor scale), and no inf / nan
+    may appear."""
     from nsgp_repre_amd import ops
-    D, rows = 256, 128
+    D, rows = 256, 256
     g = torch.Generator().manual_seed(21)
     sv, V = O.eigens(torch.from_numpy(I.covariance_like(D, 33, rows_mult=2)))
     P = O.build_projector(V, O.adaptive_threshold(sv, 0.0), True)
-    for gscale, row_scale, pscale in ((1e4, 1.0, 1.0), (1e-6, 1.0, 1.0), (1.0, 1e-6, 1.0), (1.0, 1.0, 1e-7), (0.0, 1.0, 1.0)):
+    col_decades = torch.pow(10.0, -6.0 * (torch.arange(D) % 24) / 23.0)
+    for gscale, row_scale, pscale, cols in ((1e4, 1.0, 1.0, False), (1e-6, 1.0, 1.0, False), (1.0, 1e-6, 1.0, False),
+                                            (1.0, 1.0, 1e-7, False), (1.0, 1e-6, 1.0, True), (0.0, 1.0, 1.0, False)):
         grad = torch.randn(rows, D, generator=g) * gscale
-        grad[: rows // 2] *= row_scale
-        Pc = P * pscale
+        grad[::2] *= row_scale                                   # every other row: neighbours inside one MFMA block differ
+        Pc = P * pscale * (col_decades[None, :] if cols else 1.0)
         p = torch.nn.Parameter(torch.zeros(rows, D, device=dev))
         opt = N.SGDNSCL([p], lr=1.0, momentum=0.0, svd=True)
         opt.param_groups[0]["names"] = ["backbone.w.weight"]
@@ -554,13 +669,19 @@ def test_f16x2_split_survives_a_wide_dynamic_range(N, dev):
         opt.split_mfma = "f16x2"
         p.grad = grad.clone().to(dev)
         opt.step()
-        assert opt.uses_split_mfma() == "f16x2"
+        assert opt.uses_split_mfma() == "f16x2" and opt.tile_counts() == (0, 0, 2)
         got = p.detach().cpu()
-        want = (-(grad.double()) @ Pc.double())
         assert torch.isfinite(got).all()
-        assert (got.double() - want).abs().max().item() <= REL * max(want.abs().max().item(), 1e-300), (gscale, row_scale, pscale)
-    sp, sc = ops.split_projector_f16(P.to(dev))
-    assert 2.0 ** 13 <= float(P.abs().max()) * sc < 2.0 ** 14 and sp.dtype == torch.float16
+        want = (-(grad.double()) @ Pc.double())
+        assert _row_rel(got, want) <= REL, (gscale, row_scale, pscale, cols, _row_rel(got, want))
+        if cols:    # and column by column: a column-scaled projector keeps fp32-level accuracy in its small columns
+            assert _row_rel(got.t().contiguous(), want.t().contiguous()) <= REL
+    buf = ops.split_projector_f16(P.to(dev))
+    terms, c, cinv = ops.unpack_split_f16(buf, D)
+    colmax = P.abs().amax(0).to(dev)
+    assert bool(((colmax * c >= 2.0 ** 13) & (colmax * c < 2.0 ** 14)).all()) and bool((c * cinv == 1).all())
+    back = (terms[0].double() + terms[1].double()) * cinv.double()[:, None]          # [n][k] = P^T
+    assert (back.t() - P.to(dev).double()).abs().max().item() <= 2.0 ** -21 * float(P.abs().max())
 
 
 def test_param_groups_with_different_hyperparameters(N, dev):
@@ -618,38 +739,6 @@ def test_adamw_param_groups(N, dev):
 
 
 # ------------------------------------------------------------------ the other BASELINE configs as parity cases
-@pytest.mark.parametrize("split", [False, "bf16x3", "f16x2"])
-def test_r101_table_one_step_vs_torch_gpu(N, dev, split):
-    """configs[4] (R-101-FPN): 101 projected layers, 175.9 GFLOP, one plan."""
-    layers = O.resnet_fpn_projected_layers(101)
-    gen = torch.Generator(device="cpu").manual_seed(8)
-    params, names, Ps, cache = [], [], {}, {}
-    for n, cout, D in layers:
-        k = 3 if (("conv2" in n) or ("fpn_convs" in n)) else 1
-        params.append(torch.nn.Parameter((torch.randn(cout, D // (k * k), k, k, generator=gen) * 0.02).to(dev)))
-        names.append(n)
-        if D not in cache:
-            cache[D] = (torch.randn(D, D, generator=gen) / D ** 0.5).to(dev)
-        Ps[n] = cache[D]
-    opt = N.SGDNSCL(params, lr=0.02, momentum=0.9, weight_decay=1e-4, svd=True)
-    opt.param_groups[0]["names"] = names
-    for n, P in Ps.items():
-        opt.transforms[n] = P
-    opt.split_mfma = split
-    before = [p.detach().clone() for p in params]
-    grads = [torch.randn(p.shape, generator=gen).to(dev) for p in params]
-    for p, gr in zip(params, grads):
-        p.grad = gr.clone()
-    opt.step()
-    torch.cuda.synchronize()
-    flops, _, ntiles, nproj = opt.plan_stats()
-    assert nproj == 101 and abs(flops / 1e9 - 175.9) < 0.05 and ntiles == 2778 and opt.uses_split_mfma() == split
-    for n, p, p0, gr in zip(names, params, before, grads):
-        upd = -(0.02 * (gr + 1e-4 * p0))
-        exp = p0 + (upd.view(upd.shape[0], -1) @ Ps[n]).view_as(upd)
-        assert _rel(p - p0, exp - p0) <= 2e-5, n
-
-
 def test_coco_40_40_sized_bank_vs_oracle(N, dev):
     """configs[3] (COCO 40+40 task 2): 40 old classes -> K <= 400 prototypes; ragged class sizes incl. a
     class with 2 rows.  Masks and labels bit-exact vs the oracle, bank within 1e-5."""
@@ -769,13 +858,11 @@ def test_rebuilding_projectors_on_a_stepped_optimizer(N, dev, split):
     cpu = {n: init[n].clone() for n in names}
     states = [dict() for _ in names]
     hp = dict(lr=0.02, momentum=0.9, weight_decay=1e-4)
-    seen_ptrs = []
     for task in range(3):
         fea_in = {n: torch.from_numpy(I.covariance_like(int(np.prod(shapes[n][1:])), 300 + 17 * task + i, rows_mult=2)).to(dev)
                   for i, n in enumerate(names)}
         opt.get_eigens(fea_in)
         opt.get_transforms(offset=0.0)
-        seen_ptrs.append({n: opt.transforms[n].data_ptr() for n in names})
         tr_cpu = {n: opt.transforms[n].cpu() for n in names}
         for _ in range(2):
             grads = {n: torch.randn(shapes[n], generator=gen) for n in names}
@@ -786,14 +873,8 @@ def test_rebuilding_projectors_on_a_stepped_optimizer(N, dev, split):
         assert opt.uses_split_mfma() == split
         torch.cuda.synchronize()
         _check(params, cpu, init, f"task{task}")
-    # the scenario the cache has to survive did occur: some projector landed on an address an EARLIER projector
-    # (of another layer or task) had occupied
-    earlier = set()
-    recycled = False
-    for ptrs in seen_ptrs:
-        recycled |= any(p in earlier for p in ptrs.values())
-        earlier |= set(ptrs.values())
-    assert recycled, "the allocator never recycled a projector address: the test lost its point"
+    if split:   # every derived copy belongs to the projector object that is installed NOW
+        assert all(opt._splits[n]["P"] is opt.transforms[n] for n in names)
     opt.close()
     assert opt._plans == [] and opt._splits == {}
     # still usable after close(): the next step builds fresh plans

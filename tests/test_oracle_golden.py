@@ -72,6 +72,52 @@ def test_g1_optimizer_steps(golden_dir, kind):
                 np.testing.assert_allclose(st[sk].numpy(), g[f"{sk}__{_key(n)}"], rtol=1e-6, atol=1e-12)
 
 
+def _row_rel(a, ref):
+    """max over rows of max_j|a - ref| / max_j|ref|  (rows = dim 0; all-zero reference rows must match exactly)."""
+    a = np.asarray(a, np.float64).reshape(a.shape[0], -1)
+    ref = np.asarray(ref, np.float64).reshape(ref.shape[0], -1)
+    err, mag = np.abs(a - ref).max(1), np.abs(ref).max(1)
+    assert (err[mag == 0] == 0).all()
+    return float((err[mag > 0] / mag[mag > 0]).max()) if (mag > 0).any() else 0.0
+
+
+@pytest.mark.parametrize("kind", list(I.G1B_KINDS))
+def test_g1b_aligned_layers_per_row(golden_dir, kind):
+    """G1b: 128-aligned layers, parameters starting at zero, gradient rows over six decades.  The oracle's first step must
+    reproduce the reference's projected update ROW BY ROW (same torch-CPU mm: 1e-6 of each row's own maximum)."""
+    g = _load(golden_dir, f"g1b_{kind}.npz")
+    gP = _load(golden_dir, "g1b_sgd.npz")
+    names, _ = I.g1b_layers()
+    hp = dict(I.G1_HYPER[kind])
+    fea_in = {n: torch.from_numpy(c) for n, c in I.g1b_covariances().items()}
+    transforms = {}
+    for n in I.g1b_projected():
+        s, V = O.eigens(fea_in[n])
+        np.testing.assert_array_equal(s.numpy(), g[f"sigma__{_key(n)}"])
+        mask = O.adaptive_threshold(s, I.G1_OFFSET, "sgd" if kind == "sgd" else "adam")
+        P = O.build_projector(V, mask, "backbone" in n)
+        Pg = gP[f"P__{_key(n)}"]
+        if kind == "sgd":
+            assert np.abs(P.numpy() - Pg).max() <= 1e-6 * np.abs(Pg).max()
+        transforms[n] = torch.from_numpy(Pg) if kind == "sgd" else P
+    params = [torch.from_numpy(a) for a in I.g1b_params()]
+    states = [dict() for _ in params]
+    for step in range(I.G1B_STEPS):
+        grads = [torch.from_numpy(a) for a in I.g1b_grads(step)]
+        STEPPERS[kind](names, params, grads, states, transforms, **hp)
+        for n, p, gr in zip(names, params, grads):
+            ref = g[f"p_step{step}__{_key(n)}"]
+            if step == 0 and n in transforms and kind == "sgd":
+                assert _row_rel(p.numpy(), ref) <= 1e-6, (kind, n)
+            assert np.abs(p.numpy() - ref).max() <= 1e-6 * max(np.abs(ref).max(), 1e-30), (kind, n, step)
+            if step == 0:
+                np.testing.assert_allclose(gr.numpy(), g[f"g_step0__{_key(n)}"], rtol=1e-6, atol=1e-9)
+    for n, st in zip(names, states):
+        for sk in ("previous_grad", "exp_avg", "exp_avg_sq"):
+            if sk in st:
+                np.testing.assert_allclose(st[sk].numpy(), g[f"{sk}__{_key(n)}"], rtol=1e-6, atol=1e-14)
+
+
 def test_g2_elbow_indices_bit_exact(golden_dir):
     g = _load(golden_dir, "g2_thresholds.npz")
     for si, s in enumerate(I.g2_spectra()):

@@ -1,0 +1,155 @@
+// Micro-benchmark + accuracy check of the second-generation fp16-split projection tile (csrc/gemm_f16x2_v2.hpp) against
+// the first-generation one (csrc/gemm_f16x2.hpp), on uniform GEMMs with a wide per-row / per-column dynamic range.
+// build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -I nsgp-repre_amd/csrc -o gpurun_out/proj_v2_bench tools/proj_v2_bench.hip
+#include <hip/hip_runtime.h>
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <vector>
+#include "gemm_f16x2_v2.hpp"
+using namespace nsgp;
+
+#define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at line %d\n", hipGetErrorString(e_), __LINE__); return 1; } } while (0)
+
+// out[m][n] = rinv[m] * cinv[n] * (A_split x B_split)[m][n]
+template <int MB>
+__global__ __launch_bounds__(V2_THREADS, 2) void v2_kernel(const void* As, const void* Bs, const float* rinv, const float* cinv,
+                                                           float* C, int M, int N, int K) {
+    extern __shared__ __attribute__((aligned(16))) char smem_c[];
+    f32x16 acc[2][2];
+    zero_acc(acc);
+    const int m0 = blockIdx.y * (MB * 64), n0 = blockIdx.x * 128;
+    gemm_tile_f16x2_v2<MB>(As, m0 / 64, Bs, n0 / 64, K, smem_c, acc);
+    if ((int)(threadIdx.x >> 6) >= 2 * MB) return;
+    float* smem = reinterpret_cast<float*>(smem_c);
+    acc_to_lds(smem, acc);
+    __builtin_amdgcn_s_waitcnt(0xc07f);
+    for_each_row4(smem, [&](int r, int col, float4 v) {
+        const float ri = rinv[m0 + r];
+        const f32x4 ci = *(const gf32x4*)(cinv + n0 + col);
+        f32x4 o;
+        o[0] = ri * (ci[0] * v.x); o[1] = ri * (ci[1] * v.y); o[2] = ri * (ci[2] * v.z); o[3] = ri * (ci[3] * v.w);
+        *(gf32x4*)(C + (size_t)(m0 + r) * N + n0 + col) = o;
+    });
+}
+
+// first-generation tile, one scale per operand matrix
+__global__ __launch_bounds__(256, 2) void v1_kernel(const float* A, const _Float16* Bt, float* C, int M, int N, int K, float sa, float unscale) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    f32x16 acc[2][2];
+    zero_acc(acc);
+    const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+    gemm_tile_f16x2(A, K, Bt, K, m0, n0, sa, smem, acc);
+    acc_to_lds(smem, acc);
+    __builtin_amdgcn_s_waitcnt(0xc07f);
+    for_each_row4(smem, [&](int r, int col, float4 v) {
+        f32x4 o;
+        o[0] = unscale * v.x; o[1] = unscale * v.y; o[2] = unscale * v.z; o[3] = unscale * v.w;
+        *(gf32x4*)(C + (size_t)(m0 + r) * N + n0 + col) = o;
+    });
+}
+
+template <class F>
+static float time_it(F f, int reps = 10) {
+    hipEvent_t e0, e1; (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
+    std::vector<float> ts;
+    for (int i = 0; i < reps; ++i) {
+        (void)hipEventRecord(e0, 0); f(); (void)hipEventRecord(e1, 0); (void)hipEventSynchronize(e1);
+        float ms; (void)hipEventElapsedTime(&ms, e0, e1);
+        if (i >= 2) ts.push_back(ms);
+    }
+    std::sort(ts.begin(), ts.end());
+    return ts[ts.size() / 2];
+}
+
+static int run_shape(int M, int N, int K, bool wide_rows) {
+    float *A, *B, *C, *rinv, *cscale, *cinv; void *As, *Bs; _Float16* Bt1;
+    CK(hipMalloc(&A, (size_t)M * K * 4)); CK(hipMalloc(&B, (size_t)K * N * 4)); CK(hipMalloc(&C, (size_t)M * N * 4));
+    CK(hipMalloc(&As, v2_operand_bytes(M, K))); CK(hipMalloc(&Bs, v2_operand_bytes(N, K))); CK(hipMalloc(&Bt1, (size_t)N * K * 4));
+    CK(hipMalloc(&rinv, M * 4)); CK(hipMalloc(&cscale, N * 4)); CK(hipMalloc(&cinv, N * 4));
+    std::vector<float> ha((size_t)M * K), hb((size_t)K * N);
+    unsigned s = 12345u + M + 3 * K;
+    auto rnd = [&]() { s = s * 1664525u + 1013904223u; return ((s >> 8) & 0xffff) / 32768.0f - 1.0f; };
+    // rows of A span 8 decades, columns of B 6 decades, a quarter of the entries inside a row 4 decades smaller than the rest
+    std::vector<float> rs(M), cs(N);
+    for (int m = 0; m < M; ++m) rs[m] = wide_rows ? powf(10.0f, -8.0f * ((m * 37) % 64) / 63.0f) : 1.0f;
+    for (int n = 0; n < N; ++n) cs[n] = wide_rows ? powf(10.0f, -6.0f * ((n * 11) % 32) / 31.0f) : 1.0f;
+    for (int m = 0; m < M; ++m) for (int k = 0; k < K; ++k) { float v = rnd() * 1e-3f * rs[m]; if ((s & 0x300) == 0) v *= 1e-4f; ha[(size_t)m * K + k] = v; }
+    for (int k = 0; k < K; ++k) for (int n = 0; n < N; ++n) { float v = rnd() * 0.05f * cs[n]; if ((s & 0xc00) == 0) v *= 1e-5f; hb[(size_t)k * N + n] = v; }
+    CK(hipMemcpy(A, ha.data(), ha.size() * 4, hipMemcpyHostToDevice)); CK(hipMemcpy(B, hb.data(), hb.size() * 4, hipMemcpyHostToDevice));
+    float ma = 0, mb = 0; for (float v : ha) ma = std::max(ma, fabsf(v)); for (float v : hb) mb = std::max(mb, fabsf(v));
+    union { float f; unsigned u; } cv; cv.f = ma; const float sa = f2_scale_from_amax_bits(cv.u); cv.f = mb; const float sb = f2_scale_from_amax_bits(cv.u);
+    CK(hipFuncSetAttribute(reinterpret_cast<const void*>(v2_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, V2_SMEM_BYTES));
+    CK(hipFuncSetAttribute(reinterpret_cast<const void*>(v2_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, V2_SMEM_BYTES));
+    CK(hipFuncSetAttribute(reinterpret_cast<const void*>(v1_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, F2_SMEM_BYTES));
+    // operand preparation (timed: the projector's is once per task, the update's is fused into the elementwise launch in the library)
+    const float t_rows = time_it([&] { hipLaunchKernelGGL(nsgp_split_rows_f16x2_kernel, dim3(M / 8), dim3(256), 0, 0, A, M, K, As, rinv); });
+    const float t_cols = time_it([&] {
+        hipLaunchKernelGGL(nsgp_col_scales_f16x2_kernel, dim3((N + 31) / 32), dim3(256), 0, 0, B, K, N, cscale, cinv);
+        hipLaunchKernelGGL(nsgp_split_transpose_f16x2_v2_kernel, dim3((N + 31) / 32, (K + 31) / 32), dim3(256), 0, 0, B, K, N, cscale, Bs);
+    });
+    hipLaunchKernelGGL(nsgp_split_transpose_f16x2_kernel, dim3((N + 31) / 32, (K + 31) / 32), dim3(256), 0, 0, B, K, N, sb, Bt1);
+    CK(hipDeviceSynchronize());
+    const double fl = 2.0 * M * N * (double)K;
+    std::vector<float> c1((size_t)M * N), c2((size_t)M * N), c3((size_t)M * N);
+    const float t1 = time_it([&] { hipLaunchKernelGGL(v1_kernel, dim3(N / 128, M / 128), dim3(256), F2_SMEM_BYTES, 0, A, Bt1, C, M, N, K, sa, 1.0f / (sa * sb)); });
+    CK(hipMemcpy(c1.data(), C, c1.size() * 4, hipMemcpyDeviceToHost));
+    CK(hipMemset(C, 0, (size_t)M * N * 4));
+    float t4 = 0;
+    if (M % 256 == 0) {
+        t4 = time_it([&] { hipLaunchKernelGGL(v2_kernel<4>, dim3(N / 128, M / 256), dim3(V2_THREADS), V2_SMEM_BYTES, 0, As, Bs, rinv, cinv, C, M, N, K); });
+        CK(hipGetLastError());
+        CK(hipMemcpy(c2.data(), C, c2.size() * 4, hipMemcpyDeviceToHost));
+    }
+    CK(hipMemset(C, 0, (size_t)M * N * 4));
+    const float t2 = time_it([&] { hipLaunchKernelGGL(v2_kernel<2>, dim3(N / 128, M / 128), dim3(V2_THREADS), V2_SMEM_BYTES, 0, As, Bs, rinv, cinv, C, M, N, K); });
+    CK(hipGetLastError());
+    CK(hipMemcpy(c3.data(), C, c3.size() * 4, hipMemcpyDeviceToHost));
+    // race screen: repeat the MB=4 launch and require bit-identical output every time
+    int unstable = 0;
+    if (M % 256 == 0) {
+        std::vector<float> cr((size_t)M * N);
+        for (int rep = 0; rep < 6; ++rep) {
+            CK(hipMemset(C, 0, (size_t)M * N * 4));
+            hipLaunchKernelGGL(v2_kernel<4>, dim3(N / 128, M / 256), dim3(V2_THREADS), V2_SMEM_BYTES, 0, As, Bs, rinv, cinv, C, M, N, K);
+            CK(hipMemcpy(cr.data(), C, cr.size() * 4, hipMemcpyDeviceToHost));
+            for (size_t i = 0; i < cr.size(); ++i) if (cr[i] != c2[i] && !(cr[i] != cr[i] && c2[i] != c2[i])) { ++unstable; break; }
+        }
+    }
+    // accuracy per output ROW against fp64: sampled rows, all columns
+    double worst1 = 0, worst2 = 0, worst3 = 0, tmax1 = 0, tmax2 = 0, tref = 0, d23 = 0;
+    const int NS = 24;
+    std::vector<double> ref(N);
+    for (int smp = 0; smp < NS; ++smp) {
+        const int i = (int)(((long)smp * 2654435761u) % M);
+        std::fill(ref.begin(), ref.end(), 0.0);
+        for (int k = 0; k < K; ++k) { const double a = ha[(size_t)i * K + k]; const float* br = &hb[(size_t)k * N]; for (int j = 0; j < N; ++j) ref[j] += a * (double)br[j]; }
+        double rmax = 0, e1 = 0, e2 = 0, e3 = 0;
+        for (int j = 0; j < N; ++j) {
+            rmax = std::max(rmax, fabs(ref[j]));
+            e1 = std::max(e1, fabs(c1[(size_t)i * N + j] - ref[j])); e2 = std::max(e2, fabs(c2[(size_t)i * N + j] - ref[j])); e3 = std::max(e3, fabs(c3[(size_t)i * N + j] - ref[j]));
+            d23 = std::max(d23, (double)fabsf(c2[(size_t)i * N + j] - c3[(size_t)i * N + j]));
+        }
+        worst1 = std::max(worst1, e1 / rmax); worst2 = std::max(worst2, e2 / rmax); worst3 = std::max(worst3, e3 / rmax);
+        tmax1 = std::max(tmax1, e1); tmax2 = std::max(tmax2, e2); tref = std::max(tref, rmax);
+    }
+    printf("M %d N %d K %d %s\n", M, N, K, wide_rows ? "(rows over 8 decades, columns over 6)" : "(uniform magnitudes)");
+    printf("  gen-1 128x128 tile, per-tensor scales : %.3f ms = %6.1f TF fp32-equivalent | worst per-row rel err %.3g | tensor-max rel err %.3g\n", t1, fl / t1 / 1e9, worst1, tmax1 / tref);
+    if (M % 256 == 0)
+        printf("  gen-2 256x128 tile, row/col scales    : %.3f ms = %6.1f TF fp32-equivalent | worst per-row rel err %.3g | tensor-max rel err %.3g | unstable repeats %d\n", t4, fl / t4 / 1e9, worst2, tmax2 / tref, unstable);
+    printf("  gen-2 128x128 (MB=2) tile             : %.3f ms = %6.1f TF fp32-equivalent | worst per-row rel err %.3g | max|MB4 - MB2| on the sampled rows %.3g\n", t2, fl / t2 / 1e9, worst3, M % 256 == 0 ? d23 : -1.0);
+    printf("  operand preparation: row split of A %.3f ms (%.2f TB/s of read+write), column scales + split of P^T %.3f ms\n", t_rows, 2.0 * M * K * 4 / t_rows / 1e9, t_cols);
+    (void)hipFree(A); (void)hipFree(B); (void)hipFree(C); (void)hipFree(As); (void)hipFree(Bs); (void)hipFree(Bt1); (void)hipFree(rinv); (void)hipFree(cscale); (void)hipFree(cinv);
+    return 0;
+}
+
+int main(int argc, char** argv) {
+    int rc = 0;
+    rc |= run_shape(512, 512, 512, true);        // small: 4 x 2 tiles, mostly a correctness case
+    rc |= run_shape(4096, 4096, 4096, true);
+    rc |= run_shape(4096, 4096, 4096, false);
+    rc |= run_shape(2048, 4608, 4608, true);     // four copies of the largest R-50 layer stacked (288 tiles of 256 x 128)
+    rc |= run_shape(512, 2304, 2304, true);
+    rc |= run_shape(128, 1152, 1152, true);      // Cout = 128: MB = 2 only
+    return rc;
+}
