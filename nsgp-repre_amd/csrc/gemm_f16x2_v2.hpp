@@ -22,8 +22,8 @@
 // the rows of the first-generation 128 x 128 tile: 32 B/clk/CU from L2 at full MFMA rate instead of 43.
 // LDS: three 48 KiB stages (144 of the CU's 160 KiB).  K-step t: wave w waits for ITS OWN pieces of stage t (counted vmcnt
 // that leaves step t+1's in flight), one raw s_barrier (everybody's pieces of t have landed AND everybody is done reading
-// stage t-1), issues the DMA of step t+2 into the stage t-1 used, then 16 ds_read_b128 + 24 MFMAs.  The prefetch distance is
-// two full steps (~3000 cycles); the barrier is the only synchronisation per step.
+// stage t-1); the DMA of step t+2 goes into the stage t-1 used; 16 ds_read_b128 + 24 MFMAs.  The prefetch distance is two
+// full steps (~3000 cycles); the barrier is the only synchronisation per step.
 // MB = 2 serves the 128-row layers (and a trailing 128-row remainder): the same code with waves 4-7 idle in the MFMA part.
 #pragma once
 #include "gemm_core.hpp"
@@ -51,9 +51,32 @@ __host__ __device__ __forceinline__ size_t v2_plane_offset(int block, int octet,
 }
 __host__ __device__ __forceinline__ size_t v2_operand_bytes(int rows, int K) { return (size_t)rows * K * 4; }
 
-// NB LDS-DMA pieces of one wave: piece b moves the 1 KiB at (src[b] + goff) to LDS byte address lds0 + b * V2_STEP.
-// M0 carries the LDS destination; it is compiler-reserved, so it is saved and restored around the group (one asm statement:
-// nothing can be scheduled in between).
+template <int N>
+__device__ __forceinline__ void v2_wait_vmcnt() {
+    if constexpr (N == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    else if constexpr (N == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else {
+        static_assert(N == 6, "counts: 0, 4 (MB = 2), 6 (MB = 4)");
+        asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    }
+}
+
+// raw barrier (a __syncthreads() would drain the LDS-DMA prefetch with vmcnt(0)); the empty asms keep the compiler from
+// moving LDS accesses across it
+__device__ __forceinline__ void v2_barrier() {
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+}
+
+__device__ __forceinline__ unsigned long long v2_uniform(unsigned long long x) {
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)x), hi = __builtin_amdgcn_readfirstlane((unsigned)(x >> 32));
+    return ((unsigned long long)hi << 32) | lo;
+}
+
+// NBLK LDS-DMA pieces of one wave in ONE asm statement (nothing can be scheduled in between): piece b moves the 1 KiB at
+// src[slot b] + lane * 16 to LDS byte address lds0 + slot * V2_STEP + lane * 16.  M0 carries the LDS destination; it is
+// compiler-reserved, so it is saved and restored around the group.
 template <int NBLK>
 __device__ __forceinline__ void v2_dma_group(const unsigned long long (&src)[V2_MB_MAX + V2_NB], unsigned voff, unsigned lds0) {
     unsigned keep;
@@ -86,33 +109,15 @@ __device__ __forceinline__ void v2_dma_group(const unsigned long long (&src)[V2_
     }
 }
 
-template <int N>
-__device__ __forceinline__ void v2_wait_vmcnt() {
-    if constexpr (N == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    else if constexpr (N == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-    else {
-        static_assert(N == 6, "counts: 0, 4 (MB = 2), 6 (MB = 4)");
-        asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-    }
-}
-
-// raw barrier (a __syncthreads() would drain the LDS-DMA prefetch with vmcnt(0)); the empty asms keep the compiler from
-// moving LDS accesses across it
-__device__ __forceinline__ void v2_barrier() {
-    asm volatile("" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    asm volatile("" ::: "memory");
-}
-
-__device__ __forceinline__ unsigned long long v2_uniform(unsigned long long x) {
-    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)x), hi = __builtin_amdgcn_readfirstlane((unsigned)(x >> 32));
-    return ((unsigned long long)hi << 32) | lo;
-}
-
 // acc += A[rows of blocks a_block0 .. +MB) x B[cols of blocks b_block0, b_block0 + 1), both pre-tiled / pre-split with K
 // columns (K % 32 == 0).  512 threads.  On return every wave has passed a barrier after its last LDS read and no DMA is
 // in flight: the ring is free for the caller's epilogue.
-template <int MB>
+// Study knobs (tools/proj_v2_bench.hip; profiles/r02/proj_v2_schedule_study.log), defaults = what measured best at
+// sustained clocks:  STAGGER -- the two waves that share a SIMD (w and w + 4) issue their DMA pieces at different points of
+// the step (waves 4-7 between the two k16 halves): -5 %.  PATTERN -- the LDS-read / MFMA interleave pinned with
+// sched_group_barriers: 0 = 8 reads, (MFMA, read) x 8, 16 MFMAs; 1 = all 16 reads first; 2 = the compiler's own; 3 = 4 reads,
+// (MFMA, read) x 12: all within 2 %.  (The v_mfma_f32_16x16x32_f16 form of the same step measured the same 415 TF-eq.)
+template <int MB, bool STAGGER = false, int PATTERN = 0>
 __device__ __forceinline__ void gemm_tile_f16x2_v2(const void* __restrict__ Asplit, int a_block0, const void* __restrict__ Bsplit,
                                                    int b_block0, int K, char* smem, f32x16 (&acc)[2][2]) {
     static_assert(MB == 2 || MB == 4, "MB");
@@ -121,6 +126,7 @@ __device__ __forceinline__ void gemm_tile_f16x2_v2(const void* __restrict__ Aspl
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int wm = wave >> 1, wn = wave & 1;
     const size_t blk = (size_t)K * 256;                                 // bytes of one 64-row block
+    // block slots of a stage: 0..3 = A row blocks, 4..5 = B column blocks; MB = 2 leaves slots 2, 3 unused
     unsigned long long src[V2_MB_MAX + V2_NB];
 #pragma unroll
     for (int b = 0; b < V2_MB_MAX; ++b)
@@ -142,13 +148,17 @@ __device__ __forceinline__ void gemm_tile_f16x2_v2(const void* __restrict__ Aspl
     const lds_char* abase = (const lds_char*)smem + wm * V2_STEP + h * (2 * V2_PLANE) + r * 16;
     const lds_char* bbase = (const lds_char*)smem + (V2_MB_MAX + wn) * V2_STEP + h * (2 * V2_PLANE) + r * 16;
     const bool active = wm < MB;       // MB = 2: waves 4-7 only move data
+    typedef const __attribute__((address_space(3))) h16x8* lds_frag;
     // One step = 16 ds_read_b128 (two k16 halves x {a0, a1, b0, b1} x two 32-row blocks) + 24 MFMAs.  The schedule is pinned
-    // with sched_group_barriers: the 8 reads of the first half, then the second half's reads one by one BETWEEN the first
-    // half's MFMAs, then the remaining MFMAs -- left alone, hipcc issues 4 reads, waits, 4 MFMAs, ... with the matrix pipe idle
-    // during every wait.
-    auto compute = [&](auto st) {
-        constexpr int ST = decltype(st)::value;
-        if (!active) return;
+    // with sched_group_barriers: four reads, then one read behind each of the next twelve MFMAs, then the remaining MFMAs --
+    // left alone, hipcc issues 4 reads, waits, 4 MFMAs, ... with the matrix pipe idle during every wait.
+    auto compute = [&](auto st, auto st_dma, auto late_dma) {
+        constexpr int ST = decltype(st)::value, SD = decltype(st_dma)::value;
+        constexpr bool LATE = decltype(late_dma)::value != 0;        // issue this step's DMA between the k16 halves
+        if (!active) {
+            if (LATE) issue(SD);
+            return;
+        }
         h16x8 fa[2][2][2], fb[2][2][2];     // [k16 half][32-row block][term]
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks)
@@ -156,14 +166,10 @@ __device__ __forceinline__ void gemm_tile_f16x2_v2(const void* __restrict__ Aspl
             for (int p = 0; p < 2; ++p)
 #pragma unroll
                 for (int i = 0; i < 2; ++i) {
-                    fa[ks][i][p] = *reinterpret_cast<const __attribute__((address_space(3))) h16x8*>(
-                        abase + ST * V2_STAGE + ks * (4 * V2_PLANE) + p * V2_PLANE + i * 512);
-                    fb[ks][i][p] = *reinterpret_cast<const __attribute__((address_space(3))) h16x8*>(
-                        bbase + ST * V2_STAGE + ks * (4 * V2_PLANE) + p * V2_PLANE + i * 512);
+                    fa[ks][i][p] = *reinterpret_cast<lds_frag>(abase + ST * V2_STAGE + ks * (4 * V2_PLANE) + p * V2_PLANE + i * 512);
+                    fb[ks][i][p] = *reinterpret_cast<lds_frag>(bbase + ST * V2_STAGE + ks * (4 * V2_PLANE) + p * V2_PLANE + i * 512);
                 }
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-            // smallest terms first; consecutive MFMAs belong to four independent accumulator chains
+        auto half = [&](int ks) {           // smallest terms first; consecutive MFMAs belong to four independent accumulator chains
 #pragma unroll
             for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
@@ -176,32 +182,78 @@ __device__ __forceinline__ void gemm_tile_f16x2_v2(const void* __restrict__ Aspl
             for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
                 for (int ni = 0; ni < 2; ++ni) acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[ks][mi][0], fb[ks][ni][0], acc[mi][ni], 0, 0, 0);
-        }
-        __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);        // 8 DS reads (first k16 half)
+        };
+        half(0);
+        if (LATE) {     // region 1: all 16 reads + the first k16 half's MFMAs; the DMA group; region 2: the second half's MFMAs
+            if (PATTERN == 0) {
+                __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);    // 1 MFMA
-            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);    // 1 DS read (second half)
+                for (int i = 0; i < 8; ++i) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                }
+                __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+            } else if (PATTERN == 1) {
+                __builtin_amdgcn_sched_group_barrier(0x100, 16, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, 12, 0);
+            } else if (PATTERN == 3) {
+                __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
+#pragma unroll
+                for (int i = 0; i < 12; ++i) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            issue(SD);
+            __builtin_amdgcn_sched_barrier(0);
+            half(1);
+        } else {
+            half(1);
+            if (PATTERN == 0) {             // 8 reads, one read behind each of the next 8 MFMAs, the other 16 MFMAs
+                __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                }
+                __builtin_amdgcn_sched_group_barrier(0x008, 16, 0);
+            } else if (PATTERN == 1) {
+                __builtin_amdgcn_sched_group_barrier(0x100, 16, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, 24, 0);
+            } else if (PATTERN == 3) {
+                __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
+#pragma unroll
+                for (int i = 0; i < 12; ++i) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                }
+                __builtin_amdgcn_sched_group_barrier(0x008, 12, 0);
+            }
         }
-        __builtin_amdgcn_sched_group_barrier(0x008, 16, 0);       // the rest
     };
-    // step t reads stage t % 3; at its top (after the barrier) the DMA of step t + 2 goes into stage (t + 2) % 3
-    auto step = [&](int t, auto st, auto st_next2) {
+    // step t reads stage t % 3; the DMA of step t + 2 goes into stage (t + 2) % 3 = the one step t - 1 read
+    auto step = [&](int t, auto st, auto st_next2, auto late) {
+        constexpr bool LATE = decltype(late)::value != 0;
         if (t + 1 < nk) v2_wait_vmcnt<NBLK>(); else v2_wait_vmcnt<0>();
         v2_barrier();
-        if (t + 2 < nk) issue(decltype(st_next2)::value);
-        compute(st);
+        const bool dma = t + 2 < nk;
+        if (dma && !LATE) issue(decltype(st_next2)::value);
+        if (dma && LATE) compute(st, st_next2, IC<1>{}); else compute(st, st_next2, IC<0>{});
+    };
+    auto run = [&](auto late) {
+        int t = 0;
+        for (; t + 2 < nk; t += 3) {
+            step(t, IC<0>{}, IC<2>{}, late);
+            step(t + 1, IC<1>{}, IC<0>{}, late);
+            step(t + 2, IC<2>{}, IC<1>{}, late);
+        }
+        if (t < nk) { step(t, IC<0>{}, IC<2>{}, late); ++t; }
+        if (t < nk) { step(t, IC<1>{}, IC<0>{}, late); ++t; }
     };
     issue(0);
     if (nk > 1) issue(1);
-    int t = 0;
-    for (; t + 2 < nk; t += 3) {
-        step(t, IC<0>{}, IC<2>{});
-        step(t + 1, IC<1>{}, IC<0>{});
-        step(t + 2, IC<2>{}, IC<1>{});
-    }
-    if (t < nk) { step(t, IC<0>{}, IC<2>{}); ++t; }
-    if (t < nk) { step(t, IC<1>{}, IC<0>{}); ++t; }
+    if (STAGGER && wave >= 4) run(IC<1>{}); else run(IC<0>{});
     v2_barrier();                      // everybody is done reading: the ring is the caller's
 }
 

@@ -12,14 +12,14 @@ using namespace nsgp;
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at line %d\n", hipGetErrorString(e_), __LINE__); return 1; } } while (0)
 
 // out[m][n] = rinv[m] * cinv[n] * (A_split x B_split)[m][n]
-template <int MB>
+template <int MB, bool STAGGER = false, int PATTERN = 0>
 __global__ __launch_bounds__(V2_THREADS, 2) void v2_kernel(const void* As, const void* Bs, const float* rinv, const float* cinv,
                                                            float* C, int M, int N, int K) {
     extern __shared__ __attribute__((aligned(16))) char smem_c[];
     f32x16 acc[2][2];
     zero_acc(acc);
     const int m0 = blockIdx.y * (MB * 64), n0 = blockIdx.x * 128;
-    gemm_tile_f16x2_v2<MB>(As, m0 / 64, Bs, n0 / 64, K, smem_c, acc);
+    gemm_tile_f16x2_v2<MB, STAGGER, PATTERN>(As, m0 / 64, Bs, n0 / 64, K, smem_c, acc);
     if ((int)(threadIdx.x >> 6) >= 2 * MB) return;
     float* smem = reinterpret_cast<float*>(smem_c);
     acc_to_lds(smem, acc);
@@ -49,17 +49,18 @@ __global__ __launch_bounds__(256, 2) void v1_kernel(const float* A, const _Float
     });
 }
 
+// Sustained timing: the chip's clock settles over tens of milliseconds of back-to-back launches (a launch after 2 ms of idle
+// measures ~13 % slower than the same launch in a loop), so warm up for `warm` launches and time `reps` in ONE event pair.
 template <class F>
-static float time_it(F f, int reps = 10) {
+static float time_it(F f, int reps = 40, int warm = 40) {
     hipEvent_t e0, e1; (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
-    std::vector<float> ts;
-    for (int i = 0; i < reps; ++i) {
-        (void)hipEventRecord(e0, 0); f(); (void)hipEventRecord(e1, 0); (void)hipEventSynchronize(e1);
-        float ms; (void)hipEventElapsedTime(&ms, e0, e1);
-        if (i >= 2) ts.push_back(ms);
-    }
-    std::sort(ts.begin(), ts.end());
-    return ts[ts.size() / 2];
+    for (int i = 0; i < warm; ++i) f();
+    (void)hipEventRecord(e0, 0);
+    for (int i = 0; i < reps; ++i) f();
+    (void)hipEventRecord(e1, 0); (void)hipEventSynchronize(e1);
+    float ms; (void)hipEventElapsedTime(&ms, e0, e1);
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    return ms / reps;
 }
 
 static int run_shape(int M, int N, int K, bool wide_rows) {
@@ -137,6 +138,18 @@ static int run_shape(int M, int N, int K, bool wide_rows) {
     printf("  gen-1 128x128 tile, per-tensor scales : %.3f ms = %6.1f TF fp32-equivalent | worst per-row rel err %.3g | tensor-max rel err %.3g\n", t1, fl / t1 / 1e9, worst1, tmax1 / tref);
     if (M % 256 == 0)
         printf("  gen-2 256x128 tile, row/col scales    : %.3f ms = %6.1f TF fp32-equivalent | worst per-row rel err %.3g | tensor-max rel err %.3g | unstable repeats %d\n", t4, fl / t4 / 1e9, worst2, tmax2 / tref, unstable);
+    if (M % 256 == 0 && M >= 2048) {
+        auto tv = [&](auto kern) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, V2_SMEM_BYTES);
+            const float t = time_it([&] { hipLaunchKernelGGL(kern, dim3(N / 128, M / 256), dim3(V2_THREADS), V2_SMEM_BYTES, 0, As, Bs, rinv, cinv, C, M, N, K); });
+            return fl / t / 1e9;
+        };
+        printf("  gen-2 256x128 TF-eq by schedule [pattern: 0 = 8 reads,(mfma,read)x8,mfma x16 | 1 = 16 reads first | 2 = compiler | 3 = 4 reads,(mfma,read)x12]\n");
+        printf("     DMA after the barrier   : p0 %.1f  p1 %.1f  p2 %.1f  p3 %.1f\n", tv(v2_kernel<4, false, 0>), tv(v2_kernel<4, false, 1>), tv(v2_kernel<4, false, 2>), tv(v2_kernel<4, false, 3>));
+        printf("     staggered per SIMD pair : p0 %.1f  p1 %.1f  p2 %.1f  p3 %.1f\n", tv(v2_kernel<4, true, 0>), tv(v2_kernel<4, true, 1>), tv(v2_kernel<4, true, 2>), tv(v2_kernel<4, true, 3>));
+        printf("     (again) after the barrier: p0 %.1f  p1 %.1f  p2 %.1f  p3 %.1f\n", tv(v2_kernel<4, false, 0>), tv(v2_kernel<4, false, 1>), tv(v2_kernel<4, false, 2>), tv(v2_kernel<4, false, 3>));
+        printf("     (again) staggered        : p0 %.1f  p1 %.1f  p2 %.1f  p3 %.1f\n", tv(v2_kernel<4, true, 0>), tv(v2_kernel<4, true, 1>), tv(v2_kernel<4, true, 2>), tv(v2_kernel<4, true, 3>));
+    }
     printf("  gen-2 128x128 (MB=2) tile             : %.3f ms = %6.1f TF fp32-equivalent | worst per-row rel err %.3g | max|MB4 - MB2| on the sampled rows %.3g\n", t2, fl / t2 / 1e9, worst3, M % 256 == 0 ? d23 : -1.0);
     printf("  operand preparation: row split of A %.3f ms (%.2f TB/s of read+write), column scales + split of P^T %.3f ms\n", t_rows, 2.0 * M * K * 4 / t_rows / 1e9, t_cols);
     (void)hipFree(A); (void)hipFree(B); (void)hipFree(C); (void)hipFree(As); (void)hipFree(Bs); (void)hipFree(Bt1); (void)hipFree(rinv); (void)hipFree(cscale); (void)hipFree(cinv);
@@ -145,6 +158,11 @@ static int run_shape(int M, int N, int K, bool wide_rows) {
 
 int main(int argc, char** argv) {
     int rc = 0;
+    if (argc > 1) {      // schedule study only: two large shapes
+        rc |= run_shape(4096, 4096, 4096, false);
+        rc |= run_shape(4096, 4608, 4608, true);
+        return rc;
+    }
     rc |= run_shape(512, 512, 512, true);        // small: 4 x 2 tiles, mostly a correctness case
     rc |= run_shape(4096, 4096, 4096, true);
     rc |= run_shape(4096, 4096, 4096, false);

@@ -16,7 +16,7 @@ OURS = ("nsgp_", "repre_", "nsgp::")
 
 
 def short(name):
-    for key in ("nsgp_lowrank_p1_kernel", "nsgp_lowrank_p2_kernel", "nsgp_lowrank_reduce_kernel", "nsgp_project_kernel", "nsgp_update_kernel", "nsgp_project_single_kernel", "nsgp_projector_kernel",
+    for key in ("nsgp_project_v2_kernel", "nsgp_lowrank_p1_kernel", "nsgp_lowrank_p2_kernel", "nsgp_lowrank_reduce_kernel", "nsgp_project_kernel", "nsgp_update_kernel", "nsgp_project_single_kernel", "nsgp_projector_kernel",
                 "nsgp_cov_syrk_kernel", "nsgp_cov_reduce_kernel", "nsgp_batch_mean_pad_kernel", "repre_sim_mask_kernel",
                 "repre_row_norm_kernel", "repre_masked_sum_kernel"):
         if key in name:
@@ -66,10 +66,12 @@ print("summaries written to", dst)
 # gfx950 -> x2; WRITE_SIZE (KiB) is exact for 16-B-per-lane / dword stores.
 import json
 for k in agg:
-    if "nsgp_project_kernel" in k and "FETCH_SIZE" in agg[k] and "WRITE_SIZE" in agg[k]:
+    if "nsgp_project_v2_kernel<0>" not in k and "nsgp_project_v2_kernelILi0" not in k:
+        continue
+    if "FETCH_SIZE" in agg[k] and "WRITE_SIZE" in agg[k]:
         f = sum(agg[k]["FETCH_SIZE"]) / len(agg[k]["FETCH_SIZE"])
         w = sum(agg[k]["WRITE_SIZE"]) / len(agg[k]["WRITE_SIZE"])
-        json.dump({"nsgp_project_kernel_hbm_bytes_per_launch": f * 1024 * 2 + w * 1024,
+        json.dump({"kernel": k, "nsgp_project_kernel_hbm_bytes_per_launch": f * 1024 * 2 + w * 1024,
                    "fetch_size_kib_raw": f, "write_size_kib_raw": w,
                    "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE passes of `python3 bench.py --steps 10 --warmup 2 "
                              "--no-cpu-baseline` (tools/profile.sh); FETCH_SIZE x2 per the gfx950 correction"},
