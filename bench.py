@@ -1,18 +1,20 @@
-"""bench.py -- NSGP-RePRE hot path on MI355X (see DESIGN.md section 'Measurement').
+"""bench.py -- NSGP-RePRE on MI355X (see DESIGN.md section 'Measurement').
 
-One "step" = one training iteration's worth of the fork's hot path for the workload
-BASELINE.json configs[1] names (Faster R-CNN R-50-FPN, VOC 15+5 task 2, batch 1 image per GPU):
-  (1) SGDNSCL.step over the full parameter table -- 50 projected conv layers
-      (118.3 GFLOP of projection, 0.584 GB of projectors) + the un-projected tensors
-      (BN, biases, RPN, RoI head: ~14.7 M elements) -- two HIP launches;
-  (2) the RePRE replay loss on the K=150 prototype bank through a Shared2FCBBoxHeadTask-shaped
-      head (12544->1024->1024->21), forward + backward (PyTorch-ROCm GEMMs).
-The detector's own forward/backward (stock PyTorch-ROCm, SURVEY section 2.1 "out of scope")
-is NOT inside the timed region and the metric name says so.
+One "step" = ONE TRAINING ITERATION of BASELINE.json configs[1] (Faster R-CNN R-50-FPN, VOC 15+5 task 2, 1 synthetic
+3x800x1344 image per GPU): teacher predict + pseudo-label filter, student forward (RPN + RoI losses + RePRE replay loss on the
+K=150 prototype bank), backward, SGDNSCL.step (50 projected layers: 118.3 GFLOP of projection, 0.584 GB of projectors)
+and zero_grad.  `value` = whole-job training img/s over all ranks (BASELINE's metric); `nsgp_step_ms` = the two HIP launches of
+the projected optimizer step inside that very loop (HIP events recorded by the library on the launch stream), and `roofline`
+is computed from the projection launch's average duration over the same K timed steps.
 
-Multi-GPU: one process per GPU (torchrun), replicas of the same step exactly as DDP runs the
-optimizer (identical grads after all-reduce); the per-step gradient all-reduce of the 41.5 M
-fp32 parameters over RCCL IS inside the timed region for N>1.  value = images/s over all ranks.
+Multi-GPU: one process per GPU (torchrun); the detector is wrapped in DistributedDataParallel, so the bucketed RCCL all-reduce
+of the 41.5 M fp32 gradients (overlapped with backward) IS inside the timed region for N > 1; the projected step itself is
+replicated (identical gradients after the all-reduce, identical projectors) and has no exchange step of its own.
+
+Beside the headline the same JSON line carries, measured in the same process (rank 0, N = 1 only, never part of `value`):
+`hot_path` (the fork's additions alone -- SGDNSCL.step + replay loss on synthetic gradients, every MFMA path of the projection,
+the AdamW flavour, the opt-in low-rank form), `once_per_task` (covariance forward for R-50 and R-101, the 50-layer
+get_eigens + get_transforms sweep, prototype-bank builds at three sizes, the R-101 step) and `cpu_baseline`.
 """
 import argparse
 import json
@@ -53,12 +55,12 @@ def r50_fpn_voc_parameter_table():
     return table
 
 
-def r50_fpn_hooked_convs(H=800, W=1344):
-    """(name, cin, k, stride, pad, Hin, Win) of the 61 convs cal_fea_in hooks on R-50-FPN for one
-    800x1344 padded image (ignore_keys drop rpn/roi_head): sum 2*L*D^2 = 1.86 TFLOP."""
+def r50_fpn_hooked_convs(H=800, W=1344, depth=50):
+    """(name, cin, k, stride, pad, Hin, Win) of the convs cal_fea_in hooks on R-50-FPN (61) / R-101-FPN (112) for one
+    800x1344 padded image (ignore_keys drop rpn/roi_head): sum 2*L*D^2 = 1.86 / 2.77 TFLOP."""
     out = [("backbone.conv1", 3, 7, 2, 3, H, W)]
     h, w, inpl = H // 4, W // 4, 64
-    for li, (nb, planes, stride) in enumerate(((3, 64, 1), (4, 128, 2), (6, 256, 2), (3, 512, 2)), start=1):
+    for li, (nb, planes, stride) in enumerate(((3, 64, 1), (4, 128, 2), (6 if depth == 50 else 23, 256, 2), (3, 512, 2)), start=1):
         for b in range(nb):
             st = stride if b == 0 else 1
             pre = f"backbone.layer{li}.{b}"
@@ -77,14 +79,10 @@ def r50_fpn_hooked_convs(H=800, W=1344):
     return out
 
 
-def once_per_task_units(dev):
-    """The other two units of work of SURVEY 8d, timed on their own (never part of `value`):
-    one hooked covariance forward (61 convs, 1.86 TFLOP of reference FLOPs) and the VOC-15+5-sized
-    prototype-bank build (15 old classes x 300 RoIs x 12544)."""
+def _covariance_forward_ms(dev, depth):
     from nsgp_repre_amd import ops
-    from nsgp_repre_amd.roi_heads.prototype_bank import build_prototype_bank
     g = torch.Generator(device=dev).manual_seed(5)
-    layers = r50_fpn_hooked_convs()
+    layers = r50_fpn_hooked_convs(depth=depth)
     acts, covs, ws_bytes, ref_flops = {}, {}, 0, 0.0
     for n, cin, k, s, p, h, w in layers:
         if (cin, h, w) not in acts:
@@ -104,25 +102,106 @@ def once_per_task_units(dev):
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record(); forward(); e1.record(); torch.cuda.synchronize()
         ts.append(e0.elapsed_time(e1))
-    cov_ms = sorted(ts)[1]
-    del acts, covs, ws
-    # per class: 4 ReLU'd cluster centres + 0.6 * noise, ReLU'd (SURVEY 8d "Synthetic inputs -- RePRE")
-    centres = torch.relu(torch.randn(15, 4, 12544, device=dev, generator=g))
-    which = torch.randint(0, 4, (15, 300), device=dev, generator=g)
-    feats = torch.relu(torch.gather(centres, 1, which[..., None].expand(-1, -1, 12544))
-                       + 0.6 * torch.randn(15, 300, 12544, device=dev, generator=g)).reshape(15 * 300, 12544).contiguous()
-    cls = torch.arange(15, device=dev).repeat_interleave(300)
-    build_prototype_bank(feats, cls, [0, 15, 20], 2, 10)
+    return sorted(ts)[1], ref_flops, len(layers)
+
+
+def _bank_build(dev, n_classes, n_per_class, seed):
+    """SURVEY 8d synthetic RoIs: per class 4 ReLU'd cluster centres + 0.6 * noise, ReLU'd; wall time of the whole build
+    (similarity kernel, host-side greedy cover, masked means) and the similarity work by the reference's count 2 N^2 12544."""
+    from nsgp_repre_amd.roi_heads.prototype_bank import build_prototype_bank
+    g = torch.Generator(device=dev).manual_seed(seed)
+    centres = torch.relu(torch.randn(n_classes, 4, 12544, device=dev, generator=g))
+    which = torch.randint(0, 4, (n_classes, n_per_class), device=dev, generator=g)
+    feats = torch.empty(n_classes * n_per_class, 12544, device=dev)
+    for c in range(n_classes):      # class by class: the 20,000-row class is 1 GB on its own
+        feats[c * n_per_class:(c + 1) * n_per_class] = torch.relu(centres[c][which[c]] + 0.6 * torch.randn(n_per_class, 12544, device=dev, generator=g))
+    cls = torch.arange(n_classes, device=dev).repeat_interleave(n_per_class)
+    split = [0, n_classes, n_classes + 5]
+    if n_per_class <= 2000:
+        build_prototype_bank(feats, cls, split, 2, 10)       # warm-up
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    bank, labels, _, _ = build_prototype_bank(feats, cls, [0, 15, 20], 2, 10)
+    bank, labels, _, _ = build_prototype_bank(feats, cls, split, 2, 10)
     torch.cuda.synchronize()
-    bank_ms = (time.perf_counter() - t0) * 1e3
-    return {"covariance_forward_ms": cov_ms, "covariance_reference_flops": ref_flops,
-            "covariance_tflops_by_reference_flops": ref_flops / (cov_ms * 1e-3) / 1e12,
-            "covariance_note": "61 hooked convs of R-50-FPN at 800x1344; only the upper triangle is computed (half the reference FLOPs), X never materialised",
-            "prototype_bank_build_ms": bank_ms, "prototype_bank_rows": int(bank.shape[0]),
-            "prototype_bank_note": "15 old classes x 300 RoIs x 12544 (VOC 15+5 sized), wall time incl. the host-side greedy cover"}
+    ms = (time.perf_counter() - t0) * 1e3
+    flops = n_classes * 2.0 * n_per_class * n_per_class * 12544
+    return {"classes": n_classes, "rois_per_class": n_per_class, "build_ms": ms, "bank_rows": int(bank.shape[0]),
+            "similarity_reference_flops": flops, "tflops_by_reference_flops": flops / (ms * 1e-3) / 1e12}
+
+
+def once_per_task_units(N, dev):
+    """The once-per-task units of work of SURVEY 8d, each timed on its own (never part of `value`)."""
+    out = {}
+    for depth in (50, 101):
+        ms, ref_flops, n = _covariance_forward_ms(dev, depth)
+        out[f"covariance_forward_r{depth}"] = {
+            "ms": ms, "hooked_convs": n, "reference_flops": ref_flops, "tflops_by_reference_flops": ref_flops / (ms * 1e-3) / 1e12,
+            "note": "one hooked forward at 800x1344 (fp32 activations); only the upper triangle is computed (half the reference FLOPs), X never materialised"}
+    torch.cuda.empty_cache()
+    # a5 -> a7: spectra and projectors of all 50 projected layers from SURVEY 8d's seeded covariances (runner:635-662)
+    import nsgp_oracle as O
+    layers = O.resnet_fpn_projected_layers(50)
+    params, names, fea_in = [], [], {}
+    for idx, (n, cout, D) in enumerate(layers):
+        params.append(torch.nn.Parameter(torch.empty(cout, D, device=dev)))
+        names.append(n)
+        gen = torch.Generator(device=dev).manual_seed(2000 + idx)
+        X = torch.randn(4 * D, D, device=dev, generator=gen) * torch.logspace(0, -3, D, device=dev)[None, :]
+        fea_in[n] = (X.t() @ X).contiguous()
+        del X
+    opt = N.SGDNSCL(params, lr=0.02, momentum=0.9, weight_decay=1e-4, svd=True)
+    opt.param_groups[0]["names"] = names
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    opt.get_eigens(fea_in)
+    torch.cuda.synchronize()
+    t1 = time.perf_counter()
+    opt.get_transforms(offset=0.0)
+    torch.cuda.synchronize()
+    t2 = time.perf_counter()
+    ranks = {n: int(opt.eigens[n]["eigen_value"].shape[0] - round(float(torch.trace(opt.transforms[n]) ** 2 / (opt.transforms[n] ** 2).sum())))
+             for n in names[:3]}
+    out["eigens_and_transforms_r50"] = {
+        "get_eigens_ms": (t1 - t0) * 1e3, "get_transforms_ms": (t2 - t1) * 1e3, "layers": len(layers),
+        "eigensolver": "torch.linalg.eigh (rocSOLVER syevd) per layer -- a library call", "projector_kernel": "nsgp_projector_kernel (HIP SYRK)",
+        "note": "the reference runs torch.svd on every rank, twice (runner:554-555); under DDP the product shards the layers over the ranks (runner/dist.py)",
+        "example_ranks_removed": ranks}
+    opt.close()
+    del opt, fea_in, params
+    torch.cuda.empty_cache()
+    # prototype-bank builds: VOC 15+5 sized, COCO 40+40 average class, COCO 'person'-sized stress class (SURVEY 8d)
+    out["prototype_bank"] = [_bank_build(dev, 15, 300, 11), _bank_build(dev, 4, 1500, 12), _bank_build(dev, 1, 20000, 13)]
+    torch.cuda.empty_cache()
+    # R-101-FPN (configs[4]) projected step: 101 layers, 175.9 GFLOP
+    layers = O.resnet_fpn_projected_layers(101)
+    gen = torch.Generator(device=dev).manual_seed(77)
+    params, names, cache = [], [], {}
+    for n, cout, D in layers:
+        k = 3 if ("conv2" in n or "fpn_convs" in n) else 1
+        params.append(torch.nn.Parameter(torch.randn(cout, D // (k * k), k, k, device=dev, generator=gen) * 0.02))
+        names.append(n)
+    opt = N.SGDNSCL(params, lr=0.02, momentum=0.9, weight_decay=1e-4, svd=True)
+    opt.param_groups[0]["names"] = names
+    for (n, cout, D) in layers:
+        if D not in cache:
+            cache[D] = make_basis(D, dev, 2000 + D)
+        opt.set_basis(n, cache[D][0], cache[D][1])
+    grads = [torch.randn(p.shape, device=dev, generator=gen) * 1e-3 for p in params]
+    for p, g_ in zip(params, grads):
+        p.grad = g_
+    for _ in range(3):
+        opt.step()
+    torch.cuda.synchronize()
+    opt.profile_begin(10)
+    for _ in range(10):
+        opt.step()
+    torch.cuda.synchronize()
+    _, u_ms, g_ms = opt.profile_end()
+    flops = opt.plan_stats()[0]
+    out["r101_projected_step"] = {"layers": len(layers), "elementwise_kernel_ms": u_ms, "projection_kernel_ms": g_ms, "nsgp_step_ms": u_ms + g_ms,
+                                  "algorithmic_flops": flops, "fp32_equivalent_tflops": flops / (g_ms * 1e-3) / 1e12, "path": opt.uses_split_mfma() or "f32"}
+    opt.close()
+    return out
 
 
 def make_basis(D, dev, seed):
@@ -188,37 +267,53 @@ def cpu_baseline(table, seconds_budget=15.0):
             break
     timed = times[1:]   # first call = warm-up (thread pool, page faults)
     step_ms = sorted(timed)[len(timed) // 2] * 1e3
-    return dict(value=1e3 / step_ms, unit="img/s", cores=torch.get_num_threads(), kind="port", step_ms=step_ms,
+    return dict(value=1e3 / step_ms, unit="NSGP projected steps/s (= images/s of the hot path alone at 1 image per step; the detector is not run on the CPU side)",
+                cores=torch.get_num_threads(), kind="port", step_ms=step_ms,
                 sample=f"oracle SGDNSCL.step over the full R-50-FPN table (162 tensors, 50 projected, 118.3 GFLOP): "
                        f"1 warm-up + median of {len(timed)} steps in ~{seconds_budget:.0f} s; the replay loss is not "
                        "included on the CPU side (that favours the CPU number)")
 
 
-PEAK_BF16_MATRIX_TFLOPS = 2500.0   # dense bf16 MFMA peak (MI355X_MICROARCH.md)
+PEAK_16BIT_MATRIX_TFLOPS = 2500.0   # dense fp16 / bf16 MFMA peak (MI355X_MICROARCH.md)
 
 
-def roofline_block(split, flops, abytes, gemm_ms, update_ms, nsgp_ms, n_prof, numel, ntiles, nproj):
-    """`roofline` for the dominant kernel.  The algorithm is an fp32 contraction of 118.3 GFLOP.  On the split paths
-    every fp32 product is evaluated as three fp16 (or six bf16) MFMA products (fp32-accurate), so the
-    matrix cores EXECUTE 3 x (6 x) the algorithmic FLOPs: `achieved`/`peak`/`frac` are executed bf16 FLOP/s against the dense bf16 peak (a
-    true utilisation, <= 1), and the fp32-equivalent rate against the fp32 matrix peak is given beside it."""
+def _pmc_file():
+    for name in ("r02/traffic.json", "r01_traffic.json"):
+        f = os.path.join(ROOT, "profiles", name)
+        if os.path.exists(f):
+            return f
+    return None
+
+
+def roofline_block(split, flops, abytes_kernel, gemm_ms, update_ms, n_prof, numel, ntiles, nproj):
+    """`roofline` of the dominant kernel (the grouped projection GEMM).  The algorithm is an fp32 contraction of `flops`
+    (sum 2 Cout D^2 = 118.3 GFLOP per step for R-50-FPN -- one launch = one step's 50 layers).  `achieved` is ALGORITHMIC
+    FLOP/s = flops / the launch's average duration over the timed steps; `peak` is the dense peak of the matrix unit the kernel
+    runs on.  On the split paths every fp32 product is evaluated as three fp16 (six bf16) MFMA products, so the matrix cores
+    execute 3 x (6 x) that: reported beside it as `executed_mfma_utilisation`, never as `frac`."""
     alg_tf = flops / (gemm_ms * 1e-3) / 1e12
-    common = {"kernel_ms": gemm_ms, "elementwise_kernel_ms": update_ms, "profiled_steps": n_prof, "algorithmic_flops": flops,
-              "algorithmic_bytes": abytes, "step_hbm_frac_of_peak": abytes / (nsgp_ms * 1e-3) / 1e9 / PEAK_HBM_GBS,
-              "elementwise_kernel_hbm_gbs": 5 * 4 * numel / (update_ms * 1e-3) / 1e9, "tiles": ntiles, "layers": nproj,
-              "traffic": None, "algorithmic_fp32_equivalent_tflops": alg_tf,
-              "vs_fp32_matrix_peak": alg_tf / PEAK_FP32_MATRIX_TFLOPS}
-    if split:
-        mult = {"bf16x3": 6, "f16x2": 3}[split]
-        return {"bound": "mfma", "kernel": f"nsgp_project_kernel<SGD,fast,{split}>", "achieved": mult * alg_tf, "peak": PEAK_BF16_MATRIX_TFLOPS,
-                "unit": "TFLOP/s", "frac": mult * alg_tf / PEAK_BF16_MATRIX_TFLOPS, "executed_flops_per_algorithmic_flop": mult,
-                "note": ("three v_mfma_f32_32x32x16_f16 per fp32-equivalent product (2-term fp16 split of both operands, one power-of-two "
-                         "scale per operand matrix, fp32 accumulation)" if split == "f16x2" else
-                         "six v_mfma_f32_32x32x16_bf16 per fp32-equivalent product (3-term bf16 split of both operands, fp32 accumulation)")
-                        + "; peak = dense 16-bit MFMA peak",
-                **common}
-    return {"bound": "mfma", "kernel": "nsgp_project_kernel<SGD,fast>", "achieved": alg_tf, "peak": PEAK_FP32_MATRIX_TFLOPS, "unit": "TFLOP/s",
-            "frac": alg_tf / PEAK_FP32_MATRIX_TFLOPS, "executed_flops_per_algorithmic_flop": 1, **common}
+    mult = {"bf16x3": 6, "f16x2": 3}.get(split, 1)
+    peak = PEAK_16BIT_MATRIX_TFLOPS if split else PEAK_FP32_MATRIX_TFLOPS
+    kernel = {"f16x2": "nsgp_project_v2_kernel<SGD> (256x128 tiles, LDS-DMA, two-term fp16 split with per-row / per-column scales)",
+              "bf16x3": "nsgp_project_kernel<SGD,fast,bf16x3> (three-term bf16 split)"}.get(split, "nsgp_project_kernel<SGD,fast> (fp32 MFMA)")
+    out = {"bound": "mfma", "kernel": kernel, "achieved": alg_tf, "peak": peak, "unit": "TFLOP/s", "frac": alg_tf / peak,
+           "executed_flops_per_algorithmic_flop": mult, "executed_mfma_utilisation": mult * alg_tf / peak,
+           "vs_fp32_matrix_peak": alg_tf / PEAK_FP32_MATRIX_TFLOPS,
+           "kernel_ms": gemm_ms, "profiled_steps": n_prof, "algorithmic_flops": flops, "tiles": ntiles, "layers": nproj,
+           "algorithmic_bytes": abytes_kernel, "hbm_frac_of_peak": abytes_kernel / (gemm_ms * 1e-3) / 1e9 / PEAK_HBM_GBS,
+           "algorithmic_bytes_note": "this launch: projectors (4 B/element, read once) + the update's split copy (4 B/element) + p read and written",
+           "elementwise_kernel_ms": update_ms, "elementwise_kernel_hbm_gbs": (5 * 4 * numel) / (update_ms * 1e-3) / 1e9,
+           "elementwise_note": "nsgp_update_kernel: g r, buf r+w, p r+w = 20 B/element algorithmic (+4 B/element of split copy for projected tensors on the fp16 path)",
+           "traffic": None}
+    f = _pmc_file()
+    if f:   # HBM bytes per launch + MFMA-busy from the rocprofv3 --pmc passes of this same command (tools/profile.sh)
+        tr = json.load(open(f))
+        if split == "f16x2" or "kernel" not in tr:
+            out["traffic"] = tr.get("nsgp_project_kernel_hbm_bytes_per_launch")
+            out["traffic_source"] = tr.get("source")
+            if "mfma_busy_fraction" in tr:
+                out["mfma_busy_fraction_pmc"] = tr["mfma_busy_fraction"]
+    return out
 
 
 def end_to_end_training(N, dev, world, local_rank, basis_cache, steps, warmup, amp, batch_size=1, channels_last=False, graphs=False):
@@ -299,6 +394,11 @@ def end_to_end_training(N, dev, world, local_rank, basis_cache, steps, warmup, a
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = t.item()
     n_prof, update_ms, gemm_ms = opt.profile_end()
+    flops, _abytes, ntiles, nproj = opt.plan_stats()
+    split = opt.uses_split_mfma()
+    proj_numel = sum(p.numel() for g_ in opt.param_groups for n_, p in zip(g_["names"], g_["params"]) if n_ in opt.transforms)
+    proj_bytes = sum(P.numel() * 4 for P in opt.transforms.values())
+    all_numel = sum(p.numel() for g_ in opt.param_groups for p in g_["params"])
     for e0, e1, e2 in evs:
         fwd_bwd.append(e0.elapsed_time(e1))
         opt_ms.append(e1.elapsed_time(e2))
@@ -309,6 +409,8 @@ def end_to_end_training(N, dev, world, local_rank, basis_cache, steps, warmup, a
            "memory_format": "channels_last" if channels_last else "contiguous (NCHW)", "image": "3x800x1344 (1333x800 padded to /32)", "n_gpus": world,
            "teacher_student_fwd_bwd_ms": sum(fwd_bwd) / len(fwd_bwd), "optimizer_step_ms": sum(opt_ms) / len(opt_ms),
            "nsgp_kernels_ms": update_ms + gemm_ms, "projected_layers": n_proj,
+           "_roofline": dict(split=split, flops=flops, abytes_kernel=proj_bytes + 3 * 4 * proj_numel, gemm_ms=gemm_ms, update_ms=update_ms,
+                             n_prof=n_prof, numel=all_numel, ntiles=ntiles, nproj=nproj),
            "trainable_tensors": sum(len(g["params"]) for g in opt.param_groups),
            "losses_finite": finite, "loss_keys": sorted(losses.keys()),
            "detector_dtype": "bf16 autocast (replay-bank pass, losses, NSGP step fp32)" if amp else "f32",
@@ -317,24 +419,135 @@ def end_to_end_training(N, dev, world, local_rank, basis_cache, steps, warmup, a
                        "hipBLASLt GEMMs; teacher predict + pseudo-label filter every step, as det:65-109)"}
     if graphs:
         model.disable_graphs()
+    opt.close()
     del net, model, opt
     torch.cuda.empty_cache()
     return out
 
 
+def hot_path_only(N, dev, args, cache):
+    """The fork's additions alone (no detector): SGDNSCL.step over the full 162-tensor table + the RePRE replay loss on the K=150
+    bank, on synthetic gradients living in one flat bucket (what DDP's gradient_as_bucket_view gives).  Reported under `hot_path`."""
+    table = r50_fpn_voc_parameter_table()
+    gen = torch.Generator(device=dev).manual_seed(1234)
+    params, names = [], []
+    for n, shape, _ in table:
+        params.append(torch.nn.Parameter(torch.randn(shape, device=dev, generator=gen) * 0.02))
+        names.append(n)
+    bbox_head = N.roi_heads.Shared2FCBBoxHeadTask(in_channels=256, fc_out_channels=1024, roi_feat_size=7, num_classes=20,
+                                                  task_split=[0, 15, 20], task_id=2).to(dev)
+    for n, p in bbox_head.named_parameters():
+        params.append(p)
+        names.append("roi_head.bbox_head." + n)
+        table.append(("roi_head.bbox_head." + n, tuple(p.shape), False))
+    opt = N.SGDNSCL(params, lr=0.02, momentum=0.9, weight_decay=1e-4, svd=True)  # schedule_1x_sgdnscl.py:21
+    opt.param_groups[0]["names"] = names
+    for n, shape, proj in table:
+        if proj:
+            D = shape[1] * shape[2] * shape[3]
+            if D not in cache:
+                cache[D] = make_basis(D, dev, 2000 + D)
+            opt.set_basis(n, cache[D][0], cache[D][1])      # one [D x D] projector per layer, as in the reference
+    K = 150  # <= 10 prototypes x 15 old classes (VOC 15+5)
+
+    class Replay(N.roi_heads.PrototypeReplay):   # the product's replay_loss (head:468-501) on a synthetic bank
+        pass
+    replay = Replay()
+    replay.bbox_head, replay.task_split, replay.task_id, replay.replay = bbox_head, [0, 15, 20], 2, True
+    replay.bbox_featss = torch.relu(torch.randn(K, 12544, device=dev, generator=gen))
+    replay.tmp_label = torch.randint(0, 15, (K,), device=dev, generator=gen)
+    offs, total = [], 0
+    for p in params:
+        offs.append(total)
+        total += (p.numel() + 3) // 4 * 4
+    flat_numel_real = sum(p.numel() for p in params)
+    flat_grads = torch.zeros(total, device=dev)
+    synth_flat = torch.randn(total, device=dev, generator=gen) * 1e-3
+    for p, o in zip(params, offs):
+        p.grad = flat_grads[o:o + p.numel()].view_as(p)
+    host_step = []
+
+    def one_step():
+        flat_grads.copy_(synth_flat)           # the detector's backward() writes the grads (synthetic)
+        loss = replay.replay_loss(replay.bbox_featss)["replay_loss"]["replay_loss_cls"]   # RePRE replay loss: forward
+        loss.backward()                        # + backward: accumulates into the head's grad views
+        h0 = time.perf_counter()
+        opt.step()                             # NSGP projected step: 2 HIP launches
+        host_step.append(time.perf_counter() - h0)
+
+    def timed(steps):
+        for _ in range(3):
+            one_step()
+        torch.cuda.synchronize()
+        opt.profile_begin(steps)
+        t1 = time.perf_counter()
+        for _ in range(steps):
+            one_step()
+        torch.cuda.synchronize()
+        ms = (time.perf_counter() - t1) / steps * 1e3
+        _, u_ms, g_ms = opt.profile_end()
+        return ms, u_ms, g_ms
+
+    flops = None
+    out = {"workload": "SGDNSCL.step over 50 projected layers + 112 plain tensors (41.2M params) + replay loss fwd/bwd on K=150 prototypes; synthetic gradients",
+           "mfma_paths": {}}
+    for path in ("f16x2", "bf16x3", False):
+        opt.split_mfma = path
+        ms, u_ms, g_ms = timed(args.steps)
+        flops = opt.plan_stats()[0]
+        tf = flops / (g_ms * 1e-3) / 1e12
+        out["mfma_paths"][path or "f32"] = {
+            "uses_split_mfma": opt.uses_split_mfma(), "ms_per_step": ms, "nsgp_step_ms": u_ms + g_ms, "elementwise_kernel_ms": u_ms,
+            "projection_kernel_ms": g_ms, "fp32_equivalent_tflops": tf,
+            "frac_of_unit_peak": tf / (PEAK_16BIT_MATRIX_TFLOPS if path else PEAK_FP32_MATRIX_TFLOPS),
+            "frac_of_fp32_matrix_peak": tf / PEAK_FP32_MATRIX_TFLOPS}
+    f32 = out["mfma_paths"]["f32"]
+    out["roofline_fp32_mfma"] = {"bound": "mfma", "kernel": "nsgp_project_kernel<SGD,fast> (v_mfma_f32_32x32x2_f32, exact fp32)",
+                                 "achieved": f32["fp32_equivalent_tflops"], "peak": PEAK_FP32_MATRIX_TFLOPS, "unit": "TFLOP/s",
+                                 "frac": f32["frac_of_fp32_matrix_peak"], "kernel_ms": f32["projection_kernel_ms"]}
+    opt.split_mfma = "f16x2"
+    out["host_ms_in_optimizer_step"] = 1e3 * sum(host_step[-args.steps:]) / max(1, len(host_step[-args.steps:]))
+    # opt-in low-rank form of the same projectors (north_star: g - U(U^T g))
+    opt.low_rank = True
+    ms, u_ms, g_ms = timed(args.steps)
+    n_lr, lr_flops, lt1, lt2 = opt.lowrank_stats()
+    out["lowrank_form"] = {"ms_per_step": ms, "nsgp_step_ms": u_ms + g_ms, "projection_launches_ms": g_ms, "layers": n_lr,
+                           "algorithmic_flops": lr_flops, "achieved_tflops": lr_flops / (g_ms * 1e-3) / 1e12, "synthetic_rank": "r = D/16",
+                           "note": "opt-in (optimizer.low_rank=True); parity vs the dense form: tests/test_gpu_parity.py::test_low_rank_form_matches_dense_form"}
+    opt.low_rank = False
+    # the AdamW flavour of the same step (schedule_1x_adamwnscl.py:21) -- row a3 of SURVEY 8; parity: the G1 / G1b adamw goldens
+    adamw = N.AdamWNSCL(params, lr=1e-4, weight_decay=0.1, svd=True)
+    adamw.param_groups[0]["names"] = names
+    for n, shape, proj in table:
+        if proj:
+            adamw.transforms[n] = opt.transforms[n]
+    flat_grads.copy_(synth_flat)
+    for _ in range(3):
+        adamw.step()
+    torch.cuda.synchronize()
+    adamw.profile_begin(args.steps)
+    for _ in range(args.steps):
+        adamw.step()
+    torch.cuda.synchronize()
+    _, aw_u, aw_g = adamw.profile_end()
+    out["adamw_nscl"] = {"nsgp_step_ms": aw_u + aw_g, "elementwise_kernel_ms": aw_u, "projection_kernel_ms": aw_g,
+                         "fp32_equivalent_tflops": flops / (aw_g * 1e-3) / 1e12,
+                         "elementwise_hbm_gbs": 7 * 4 * flat_numel_real / (aw_u * 1e-3) / 1e9,
+                         "note": "AdamWNSCL.step, same table; elementwise bytes: g r, m r+w, v r+w, p r+w"}
+    adamw.close()
+    opt.close()
+    return out, table
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-end-to-end", action="store_true", help="skip the end-to-end training img/s section")
-    ap.add_argument("--e2e-steps", type=int, default=20)
-    ap.add_argument("--e2e-f32", action="store_true", help="run the detector of the end-to-end section in fp32 instead of bf16 autocast")
-    ap.add_argument("--e2e-graphs", action="store_true", help="end-to-end section with hipGraph capture of the convolutional trunk "
-                    "(measured SLOWER on this stack: 47.9 vs 44.9 ms per step, so off by default)")
-    ap.add_argument("--amp", action="store_true", help="run the replay head's GEMMs under bf16 autocast (measured 7x SLOWER "
-                    "than fp32 on this image's hipBLASLt for the M=150 shapes: 12.4 vs 1.66 ms per step, so off by default)")
+    ap.add_argument("--no-extras", action="store_true", help="headline only: skip hot_path / once_per_task / cpu_baseline")
+    ap.add_argument("--f32-detector", action="store_true", help="run the detector in fp32 instead of bf16 autocast (the NSGP step is fp32 either way)")
+    ap.add_argument("--batch-per-gpu", type=int, default=1)
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", 0))
@@ -355,203 +568,51 @@ def main():
             dist.init_process_group(backend)
     import nsgp_repre_amd as N
 
-    table = r50_fpn_voc_parameter_table()
-    gen = torch.Generator(device=dev).manual_seed(1234)
-    params, names = [], []
-    for n, shape, _ in table:
-        params.append(torch.nn.Parameter(torch.randn(shape, device=dev, generator=gen) * 0.02))
-        names.append(n)
-    # the RoI bbox head is the product's own module (Shared2FCBBoxHeadTask, VOC 15+5 task 2); its 14
-    # tensors join the optimizer table un-projected (ignore_keys=['rpn','roi_head'])
-    bbox_head = N.roi_heads.Shared2FCBBoxHeadTask(in_channels=256, fc_out_channels=1024, roi_feat_size=7, num_classes=20,
-                                                  task_split=[0, 15, 20], task_id=2).to(dev)
-    for n, p in bbox_head.named_parameters():
-        params.append(p)
-        names.append("roi_head.bbox_head." + n)
-        table.append(("roi_head.bbox_head." + n, tuple(p.shape), False))
-    opt = N.SGDNSCL(params, lr=0.02, momentum=0.9, weight_decay=1e-4, svd=True)  # schedule_1x_sgdnscl.py:21
-    opt.param_groups[0]["names"] = names
     cache = {}
-    for i, (n, shape, proj) in enumerate(table):
-        if proj:
-            D = shape[1] * shape[2] * shape[3]
-            if D not in cache:
-                cache[D] = make_basis(D, dev, 2000 + D)
-            opt.set_basis(n, cache[D][0], cache[D][1])      # one [D x D] projector per layer, as in the reference
-    K = 150  # <= 10 prototypes x 15 old classes (VOC 15+5)
-
-    class Replay(N.roi_heads.PrototypeReplay):   # the product's replay_loss (head:468-501) on a synthetic bank
-        pass
-    replay = Replay()
-    replay.bbox_head, replay.task_split, replay.task_id, replay.replay = bbox_head, [0, 15, 20], 2, True
-    replay.bbox_featss = torch.relu(torch.randn(K, 12544, device=dev, generator=gen))
-    replay.tmp_label = torch.randint(0, 15, (K,), device=dev, generator=gen)
-    # Gradients live in ONE flat bucket with 16-byte-aligned slices (what DDP's
-    # gradient_as_bucket_view gives): p.grad are views, filled by "backward" each step.
-    offs, total = [], 0
-    for p in params:
-        offs.append(total)
-        total += (p.numel() + 3) // 4 * 4
-    flat_numel_real = sum(p.numel() for p in params)
-    flat_grads = torch.zeros(total, device=dev)
-    synth_flat = torch.randn(total, device=dev, generator=gen) * 1e-3
-    for p, o in zip(params, offs):
-        p.grad = flat_grads[o:o + p.numel()].view_as(p)
-
-    host_step = []
-
-    def one_step():
-        flat_grads.copy_(synth_flat)           # the detector's backward() writes the grads (synthetic)
-        with torch.autocast("cuda", dtype=torch.bfloat16, enabled=args.amp):   # configs[1] trains under bf16 autocast (--amp)
-            loss = replay.replay_loss(replay.bbox_featss)["replay_loss"]["replay_loss_cls"]   # RePRE replay loss: forward
-        loss.backward()                        # + backward: accumulates into the head's grad views
-        h0 = time.perf_counter()
-        opt.step()                             # NSGP projected step: 2 HIP launches
-        host_step.append(time.perf_counter() - h0)
-
-    for _ in range(args.warmup):
-        one_step()
-    torch.cuda.synchronize()
-    opt.profile_begin(args.steps)
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        one_step()
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = t.item()
-
-    allreduce_ms = None
-    if world > 1:   # DDP's gradient all-reduce for this parameter set, measured on its own (not in `value`)
-        for _ in range(3):
-            dist.all_reduce(flat_grads)
-        torch.cuda.synchronize()
-        dist.barrier()
-        t_ar = time.perf_counter()
-        for _ in range(10):
-            dist.all_reduce(flat_grads)
-        torch.cuda.synchronize()
-        allreduce_ms = (time.perf_counter() - t_ar) / 10 * 1e3
-    e2e = None
-    if not args.no_end_to_end:      # every rank takes part (DDP); the hot-path numbers above are already in the bag
-        try:    # the hot-path measurement above must reach the JSON line whatever happens in this wider section
-            e2e = end_to_end_training(N, dev, world, local_rank, cache, args.e2e_steps, 3, not args.e2e_f32, graphs=args.e2e_graphs)
-            if not args.e2e_f32 and world == 1:    # the same step with an fp32 detector, for reference beside the bf16 number
-                f32 = end_to_end_training(N, dev, world, local_rank, cache, max(4, args.e2e_steps // 2), 3, False)
-                e2e["f32_detector"] = {k: f32[k] for k in ("img_s", "ms_per_step", "teacher_student_fwd_bwd_ms", "optimizer_step_ms", "losses_finite")}
-        except Exception as exc:    # reported, never hidden
-            import traceback
-            traceback.print_exc()
-            e2e = {"error": f"{type(exc).__name__}: {exc}"}
+    # ---- the headline: K full training iterations, DDP gradient all-reduce inside for N > 1
+    e2e = end_to_end_training(N, dev, world, local_rank, cache, args.steps, args.warmup, not args.f32_detector, batch_size=args.batch_per_gpu)
     if rank == 0:
-        flops, abytes, ntiles, nproj = opt.plan_stats()
-        # dominant kernel = the grouped projection GEMM: HIP events recorded by the library around
-        # that launch, on the stream it is launched on, for every one of the K timed steps
-        n_prof, update_ms, gemm_ms = opt.profile_end()
-        nsgp_ms = update_ms + gemm_ms          # both launches of SGDNSCL.step, HIP-event timed
-        ms_per_step = elapsed / args.steps * 1e3
+        rf = e2e.pop("_roofline")
         out = {
-            "metric": "NSGP-RePRE hot-path img/s (SGDNSCL projected step + RePRE replay loss; detector fwd/bwd not in the timed region) + NSGP-projection step ms",
-            "value": world * 1.0 / (ms_per_step / 1e3),
-            "unit": "img/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": ms_per_step,
-            "nsgp_step_ms": nsgp_ms,
-            "host_ms_in_optimizer_step": 1e3 * sum(host_step[-args.steps:]) / max(1, len(host_step[-args.steps:])),
+            "metric": "NSGP-RePRE training img/s (Faster R-CNN R-50-FPN, VOC 15+5 task 2: teacher + student fwd/bwd + replay loss + projected SGDNSCL step) + NSGP-projection step ms",
+            "value": e2e["img_s"], "unit": "img/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": e2e["ms_per_step"],
+            "nsgp_step_ms": rf["update_ms"] + rf["gemm_ms"],
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": {"f16x2": "f32 (parameters, gradients, state, accumulation; the projection's products as 2-term fp16 splits on the matrix cores)",
-                      "bf16x3": "f32 (parameters, gradients, state, accumulation; the projection's products as 3-term bf16 splits on the matrix cores)"
-                      }.get(opt.uses_split_mfma(), "f32"), "data": "synthetic",
-            "config": {"workload": "R-50-FPN VOC 15+5 task 2 (configs[1]): SGDNSCL step over 50 projected layers "
-                                   "+ 112 plain tensors (41.2M params), replay loss on K=150 prototypes, 1 img/GPU/step",
-                       "autocast": "bf16 for the replay head's GEMMs (as tools/train.py --amp does for the detector); parameters, gradients, optimizer state and the whole NSGP step fp32" if args.amp else "off",
-                       "global_batch": world, "parallelism": f"replicas x{world} (no exchange step on this path)" if world > 1 else "single"},
-            "ddp_grad_allreduce_ms": allreduce_ms,
-            "roofline": roofline_block(opt.uses_split_mfma(), flops, abytes, gemm_ms, update_ms, nsgp_ms, n_prof, flat_numel_real, ntiles, nproj),
+            "dtype": "f32 (NSGP step: parameters, gradients, state, accumulation; the projection's products as two-term fp16 splits on the "
+                     "matrix cores)" + ("" if args.f32_detector else "; detector forward/backward under bf16 autocast"),
+            "data": "synthetic",
+            "config": {"workload": "R-50-FPN VOC 15+5 task 2 (configs[1]), 1 synthetic 3x800x1344 image per GPU per step, 50 projected layers, K=150 prototype bank",
+                       "global_batch": world * args.batch_per_gpu, "parallelism": f"ddp{world}" if world > 1 else "single"},
+            "roofline": roofline_block(**rf),
+            "training_step": e2e,
         }
-        # opt-in low-rank form of the same projectors (north_star: g - U(U^T g)); timed separately so that
-        # the headline numbers above stay those of the dense parity path
-        if world == 1:      # the other MFMA paths of the same dense step, timed separately
-            default_path = opt.split_mfma
-            out["other_mfma_paths"] = {}
-            for other in ("f16x2", "bf16x3", False):
-                if other == opt.uses_split_mfma():
-                    continue
-                opt.split_mfma = other
-                for _ in range(3):
-                    one_step()
-                torch.cuda.synchronize()
-                opt.profile_begin(args.steps)
-                t1 = time.perf_counter()
-                for _ in range(args.steps):
-                    one_step()
-                torch.cuda.synchronize()
-                o_elapsed = (time.perf_counter() - t1) / args.steps * 1e3
-                _, o_update_ms, o_gemm_ms = opt.profile_end()
-                out["other_mfma_paths"][other or "f32"] = {
-                    "uses_split_mfma": opt.uses_split_mfma(), "ms_per_step": o_elapsed, "nsgp_step_ms": o_update_ms + o_gemm_ms,
-                    "projection_kernel_ms": o_gemm_ms, "fp32_equivalent_tflops": flops / (o_gemm_ms * 1e-3) / 1e12,
-                    "frac_of_fp32_matrix_peak": flops / (o_gemm_ms * 1e-3) / 1e12 / PEAK_FP32_MATRIX_TFLOPS}
-            opt.split_mfma = default_path
-        if world == 1:
-            opt.low_rank = True
-            for _ in range(3):
-                one_step()
-            torch.cuda.synchronize()
-            opt.profile_begin(args.steps)
-            t1 = time.perf_counter()
-            for _ in range(args.steps):
-                one_step()
-            torch.cuda.synchronize()
-            lr_elapsed = (time.perf_counter() - t1) / args.steps * 1e3
-            n_lr_prof, lr_update_ms, lr_gemm_ms = opt.profile_end()
-            n_lr, lr_flops, lt1, lt2 = opt.lowrank_stats()
-            out["lowrank_form"] = {"ms_per_step": lr_elapsed, "nsgp_step_ms": lr_update_ms + lr_gemm_ms,
-                                   "projection_launches_ms": lr_gemm_ms, "layers": n_lr, "algorithmic_flops": lr_flops,
-                                   "achieved_tflops": lr_flops / (lr_gemm_ms * 1e-3) / 1e12, "tiles_phase1": lt1, "tiles_phase2": lt2,
-                                   "synthetic_rank": "r = D/16", "note": "opt-in (optimizer.low_rank=True); parity vs the dense form: tests/test_gpu_parity.py::test_low_rank_form_matches_dense_form"}
-            opt.low_rank = False
-            # the AdamW flavour of the same step (schedule_1x_adamwnscl.py:21: lr 1e-4, weight_decay 0.1) over the same
-            # tensors, projectors and synthetic gradients -- row a3 of SURVEY 8; parity: the G1 adamw goldens
-            adamw = N.AdamWNSCL(params, lr=1e-4, weight_decay=0.1, svd=True)
-            adamw.param_groups[0]["names"] = names
-            for n, shape, proj in table:
-                if proj:
-                    adamw.transforms[n] = opt.transforms[n]
-            flat_grads.copy_(synth_flat)
-            for _ in range(3):
-                adamw.step()
-            torch.cuda.synchronize()
-            adamw.profile_begin(args.steps)
-            for _ in range(args.steps):
-                adamw.step()
-            torch.cuda.synchronize()
-            _, aw_update_ms, aw_gemm_ms = adamw.profile_end()
-            out["adamw_nscl"] = {"nsgp_step_ms": aw_update_ms + aw_gemm_ms, "elementwise_kernel_ms": aw_update_ms,
-                                 "projection_kernel_ms": aw_gemm_ms, "achieved_tflops": flops / (aw_gemm_ms * 1e-3) / 1e12,
-                                 "elementwise_hbm_gbs": 7 * 4 * flat_numel_real / (aw_update_ms * 1e-3) / 1e9,
-                                 "note": "AdamWNSCL.step, same table; elementwise bytes: g r, m r+w, v r+w, p r+w"}
-            del adamw
-        if e2e is not None:
-            out["end_to_end"] = e2e
-        if world == 1:
-            out["once_per_task"] = once_per_task_units(dev)
-        traffic_file = os.path.join(ROOT, "profiles", "r01_traffic.json")
-        if os.path.exists(traffic_file):   # HBM bytes per launch from rocprofv3 --pmc passes of this same command
-            tr = json.load(open(traffic_file))
-            out["roofline"]["traffic"] = tr.get("nsgp_project_kernel_hbm_bytes_per_launch")
-            out["roofline"]["traffic_source"] = tr.get("source")
-        if not args.no_cpu_baseline and world == 1:
-            out["cpu_baseline"] = cpu_baseline(table)
-            out["cpu_baseline"]["gpu_nsgp_step_speedup"] = out["cpu_baseline"]["step_ms"] / nsgp_ms
+        if world == 1 and not args.no_extras:
+            def guarded(name, fn):      # the headline above must reach the JSON line whatever happens in the wider sections
+                try:
+                    out[name] = fn()
+                except Exception as exc:    # reported, never hidden
+                    import traceback
+                    traceback.print_exc()
+                    out[name] = {"error": f"{type(exc).__name__}: {exc}"}
+            table_box = {}
+
+            def _hot():
+                hp, table_box["table"] = hot_path_only(N, dev, args, cache)
+                return hp
+            guarded("hot_path", _hot)
+            if not args.f32_detector:    # the same training step with an fp32 detector, beside the bf16 number
+                def _f32():
+                    r = end_to_end_training(N, dev, world, local_rank, cache, max(4, args.steps // 2), 3, False, batch_size=args.batch_per_gpu)
+                    return {k: r[k] for k in ("img_s", "ms_per_step", "teacher_student_fwd_bwd_ms", "optimizer_step_ms", "losses_finite")}
+                guarded("training_step_f32_detector", _f32)
+            guarded("once_per_task", lambda: once_per_task_units(N, dev))
+            if not args.no_cpu_baseline:
+                def _cpu():
+                    cb = cpu_baseline(table_box.get("table") or r50_fpn_voc_parameter_table())
+                    cb["gpu_nsgp_step_speedup"] = cb["step_ms"] / out["nsgp_step_ms"]
+                    return cb
+                guarded("cpu_baseline", _cpu)
         print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()
