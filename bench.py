@@ -316,7 +316,7 @@ def roofline_block(split, flops, abytes_kernel, gemm_ms, update_ms, n_prof, nume
     return out
 
 
-def end_to_end_training(N, dev, world, local_rank, basis_cache, steps, warmup, amp, batch_size=1, channels_last=False, graphs=False):
+def end_to_end_training(N, dev, world, local_rank, basis_cache, steps, warmup, amp, batch_size=1):
     """SURVEY 8(d) "end-to-end img/s": the whole task-2 training step of cl_faster_rcnn_nsgp_repre_15_5_2.py on synthetic
     800x1344 batches -- teacher predict + pseudo-label filter, student forward (RPN + RoI losses + replay loss on the
     K=150 bank), backward (DDP bucketed RCCL all-reduce overlapped with it when world > 1) and the projected SGDNSCL
@@ -345,13 +345,7 @@ def end_to_end_training(N, dev, world, local_rank, basis_cache, steps, warmup, a
             opt.set_basis(n, basis_cache[D][0], basis_cache[D][1])
             n_proj += 1
     model.train()
-    # channels_last: only the ACTIVATIONS (the input image decides the layout of every convolution's output);
-    # parameters stay contiguous -- the optimizer's [Cout x D] view of a conv weight is the reference's layout
     batches = [synthetic_batch(batch_size, (15, 20), dev, seed=100 * local_rank + i) for i in range(4)]
-    if channels_last:
-        batches = [(x.contiguous(memory_format=torch.channels_last), s) for x, s in batches]
-    if graphs:      # hipGraphs for the static-shape convolutional trunk (student fwd+bwd, teacher fwd); see detection/graphs.py
-        model.enable_graphs(batches[0][0], torch.bfloat16 if amp else None)
     net = model
     if world > 1:
         net = torch.nn.parallel.DistributedDataParallel(model, device_ids=[local_rank], broadcast_buffers=False,
@@ -405,8 +399,7 @@ def end_to_end_training(N, dev, world, local_rank, basis_cache, steps, warmup, a
     finite = all(bool(torch.isfinite(v)) for v in losses.values())
     out = {"img_s": world * batch_size * steps / elapsed, "ms_per_step": elapsed / steps * 1e3, "steps": steps, "warmup": warmup,
            "batch_per_gpu": batch_size,
-           "hip_graphs": "backbone + FPN + RPN convolutions: student forward/backward and teacher forward replayed from captured graphs" if graphs else "off",
-           "memory_format": "channels_last" if channels_last else "contiguous (NCHW)", "image": "3x800x1344 (1333x800 padded to /32)", "n_gpus": world,
+           "image": "3x800x1344 (1333x800 padded to /32)", "n_gpus": world,
            "teacher_student_fwd_bwd_ms": sum(fwd_bwd) / len(fwd_bwd), "optimizer_step_ms": sum(opt_ms) / len(opt_ms),
            "nsgp_kernels_ms": update_ms + gemm_ms, "projected_layers": n_proj,
            "_roofline": dict(split=split, flops=flops, abytes_kernel=proj_bytes + 3 * 4 * proj_numel, gemm_ms=gemm_ms, update_ms=update_ms,
@@ -417,8 +410,6 @@ def end_to_end_training(N, dev, world, local_rank, basis_cache, steps, warmup, a
            "parallelism": f"DDP x{world}: bucketed RCCL all-reduce of the gradients overlapped with backward" if world > 1 else "single",
            "detector": "nsgp_repre_amd.detection (R-50-FPN Faster R-CNN, stock recipe in plain PyTorch-ROCm: MIOpen convolutions, "
                        "hipBLASLt GEMMs; teacher predict + pseudo-label filter every step, as det:65-109)"}
-    if graphs:
-        model.disable_graphs()
     opt.close()
     del net, model, opt
     torch.cuda.empty_cache()

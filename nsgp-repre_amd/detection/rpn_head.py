@@ -82,19 +82,19 @@ class RPNHead(nn.Module):
             out.append(Instances(bboxes=boxes[keep], scores=scores[keep], labels=torch.zeros_like(keep)))
         return out
 
-    def _run(self, x, precomputed=None):
-        cls, reg = self(x) if precomputed is None else precomputed     # precomputed: the graphed trunk already ran the convs
+    def _run(self, x):
+        cls, reg = self(x)
         sizes = [c.shape[2:] for c in cls]
         anchors = self.anchors.grid(sizes, cls[0].device)
         cls_l, reg_l = self._flatten(cls, reg)
         return cls_l, reg_l, anchors
 
-    def loss_and_predict(self, x, batch_data_samples, proposal_cfg=None, precomputed=None):
-        cls_l, reg_l, anchors = self._run(x, precomputed)
+    def loss_and_predict(self, x, batch_data_samples, proposal_cfg=None):
+        cls_l, reg_l, anchors = self._run(x)
         losses = self._loss(cls_l, reg_l, anchors, batch_data_samples)
         shapes = [s.img_shape for s in batch_data_samples]
         return losses, self._proposals(cls_l, reg_l, anchors, shapes, proposal_cfg or self.PROPOSAL_TRAIN)
 
-    def predict(self, x, batch_data_samples, rescale=False, precomputed=None):
-        cls_l, reg_l, anchors = self._run(x, precomputed)
+    def predict(self, x, batch_data_samples, rescale=False):
+        cls_l, reg_l, anchors = self._run(x)
         return self._proposals(cls_l, reg_l, anchors, [s.img_shape for s in batch_data_samples], self.PROPOSAL_TEST)

@@ -70,35 +70,9 @@ class FasterRCNNRoIReplay(RoIReplayModes, _Base):
         def extract_feat(self, batch_inputs):
             return self.neck(self.backbone(batch_inputs))
 
-        def enable_graphs(self, sample_input, amp_dtype=None):
-            """Capture backbone + FPN + RPN convolutions for inputs shaped like ``sample_input`` (detection/graphs.py):
-            the student's forward/backward for ``loss`` in training mode, and -- if a teacher is attached -- the
-            teacher's forward for its per-step ``predict``.  Call after ``attach_teacher``; eval-mode passes of the
-            student (covariance hooks, RoI dump) stay eager."""
-            from ..detection.graphs import GraphedTrunk
-            object.__setattr__(self, "_graph_train", GraphedTrunk(self, sample_input, True, amp_dtype))
-            if hasattr(self, "teacher_model"):
-                t = self.teacher_model
-                object.__setattr__(t, "_graph_eval", GraphedTrunk(t, sample_input, False, amp_dtype))
-
-        def disable_graphs(self):
-            """Release the captured graphs deterministically (see ``GraphedTrunk.close``)."""
-            for owner, name in ((self, "_graph_train"), (getattr(self, "teacher_model", None), "_graph_eval")):
-                g = owner.__dict__.pop(name, None) if owner is not None else None
-                if g is not None:
-                    g.close()
-
-        def _trunk(self, batch_inputs):
-            """(feats, precomputed RPN maps or None): graph replay when one was captured for this mode and shape."""
-            g = getattr(self, "_graph_train", None) if (self.training and torch.is_grad_enabled()) else getattr(self, "_graph_eval", None)
-            if g is not None and g.matches(batch_inputs):
-                return g.run(batch_inputs)
-            return self.extract_feat(batch_inputs), None
-
         def predict(self, batch_inputs, batch_data_samples, rescale=True):
-            x, pre = self._trunk(batch_inputs)
-            kw = dict(precomputed=pre) if pre is not None else {}
-            proposals = self.rpn_head.predict(x, batch_data_samples, rescale=False, **kw)
+            x = self.extract_feat(batch_inputs)
+            proposals = self.rpn_head.predict(x, batch_data_samples, rescale=False)
             preds = self.roi_head.predict(x, proposals, batch_data_samples, rescale=rescale)
             for sample, p in zip(batch_data_samples, preds):
                 sample.pred_instances = p
@@ -132,8 +106,7 @@ class FasterRCNNRoIReplay(RoIReplayModes, _Base):
         """det:44-142: features; teacher pseudo-labels (task >= 2, unless ``mode='nullspace'``); RPN loss on the
         RPN set with labels zeroed; RoI-head loss (stock + replay) on the RoI set."""
         import copy
-        x, pre = self._trunk(batch_inputs) if hasattr(self, "_trunk") else (self.extract_feat(batch_inputs), None)
-        rpn_kw = dict(precomputed=pre) if pre is not None else {}
+        x = self.extract_feat(batch_inputs)
         rpn_data_samples = None
         if hasattr(self, "teacher_model") and use_teacher_student:
             rpn_data_samples, batch_data_samples = self.pseudo_labelled_samples(batch_inputs, batch_data_samples)
@@ -144,7 +117,7 @@ class FasterRCNNRoIReplay(RoIReplayModes, _Base):
             rpn_data_samples = rpn_data_samples if rpn_data_samples else copy.deepcopy(batch_data_samples)
             for data_sample in rpn_data_samples:                                   # class-agnostic RPN targets
                 data_sample.gt_instances.labels = torch.zeros_like(data_sample.gt_instances.labels)
-            rpn_losses, rpn_results_list = self.rpn_head.loss_and_predict(x, rpn_data_samples, proposal_cfg=proposal_cfg, **rpn_kw)
+            rpn_losses, rpn_results_list = self.rpn_head.loss_and_predict(x, rpn_data_samples, proposal_cfg=proposal_cfg)
             for key in list(rpn_losses.keys()):
                 if "loss" in key and "rpn" not in key:
                     rpn_losses[f"rpn_{key}"] = rpn_losses.pop(key)

@@ -70,39 +70,127 @@ class TaskHeadMixin:
         return cls_score, torch.cat(preds, dim=-1)
 
 
-@register(MODELS)
-class Shared2FCBBoxHeadTask(TaskHeadMixin, _Base):
-    """flatten -> (Linear + ReLU) x 2 -> per-task cls || per-task reg  (Shared2FC shape,
-    convfc_bbox_head_task.py:516-529 + forward :209-288 + get_mid_features :290-323)."""
+class _ConvReLU(nn.Module):
+    """Stand-in for mmcv's ``ConvModule(cin, cout, 3, padding=1)`` without a norm layer: same sub-module name (``conv``),
+    bias on, ReLU after -- so ``named_parameters()`` yields the reference's names (``cls_convs.0.conv.weight``)."""
 
-    def __init__(self, in_channels: int = 256, fc_out_channels: int = 1024, roi_feat_size: int = 7,
-                 num_classes: int = 80, task_split: Sequence[int] = (0, 10, 20), task_id: int = 1,
-                 reg_class_agnostic: bool = False, **kwargs):
-        if _HAVE_MMDET:  # pragma: no cover
-            super().__init__(in_channels=in_channels, roi_feat_size=roi_feat_size, num_classes=num_classes,
-                             reg_class_agnostic=reg_class_agnostic, **kwargs)
-        else:
-            nn.Module.__init__(self)
-            self.in_channels, self.num_classes = in_channels, num_classes
-        self.fc_out_channels = fc_out_channels
-        self.roi_feat_area = roi_feat_size * roi_feat_size
-        self.shared_fcs = nn.ModuleList([nn.Linear(in_channels * self.roi_feat_area, fc_out_channels),
-                                         nn.Linear(fc_out_channels, fc_out_channels)])
-        self.relu = nn.ReLU(inplace=True)
-        self._build_task_predictors(fc_out_channels, fc_out_channels, num_classes, task_split, task_id,
-                                    reg_class_agnostic)
-        self.null_space = False
-
-    def get_mid_features(self, x: torch.Tensor) -> torch.Tensor:
-        """RoI features flattened, before the shared FCs: [N, 7*7*256] (:290-323)."""
-        return x.flatten(1)
+    def __init__(self, cin: int, cout: int):
+        super().__init__()
+        self.conv = nn.Conv2d(cin, cout, 3, padding=1)
+        self.activate = nn.ReLU(inplace=True)
 
     def forward(self, x):
-        x = x.flatten(1)
-        for fc in self.shared_fcs:
+        return self.activate(self.conv(x))
+
+
+@register(MODELS)
+class ConvFCBBoxHeadTask(TaskHeadMixin, _Base):
+    """The general task head (convfc_bbox_head_task.py:14-288)::
+
+                                    /-> cls convs -> cls fcs -> per-task cls
+        shared convs -> shared fcs
+                                    \\-> reg convs -> reg fcs -> per-task reg
+
+    Constructor keywords, asserts, layer names and dimension rules follow the reference (``:60-128`` and
+    ``_add_conv_fc_branch`` ``:146-189``); the per-task predictors are ``TaskHeadMixin``'s.  Without mmdet it is a plain
+    ``nn.Module`` (no losses / targets / bbox coder -- those are stock ``BBoxHead``) and rejects keywords it cannot honour
+    instead of swallowing them."""
+
+    def __init__(self, num_shared_convs: int = 0, num_shared_fcs: int = 0, num_cls_convs: int = 0, num_cls_fcs: int = 0,
+                 num_reg_convs: int = 0, num_reg_fcs: int = 0, conv_out_channels: int = 256, fc_out_channels: int = 1024,
+                 conv_cfg=None, norm_cfg=None, init_cfg=None, task_split: Sequence[int] = (0, 10, 20), task_id: int = 1,
+                 in_channels: int = 256, roi_feat_size: int = 7, num_classes: int = 80, reg_class_agnostic: bool = False,
+                 with_avg_pool: bool = False, **kwargs):
+        if _HAVE_MMDET:  # pragma: no cover
+            super().__init__(in_channels=in_channels, roi_feat_size=roi_feat_size, num_classes=num_classes,
+                             reg_class_agnostic=reg_class_agnostic, with_avg_pool=with_avg_pool, init_cfg=init_cfg, **kwargs)
+        else:
+            if kwargs:
+                raise TypeError(f"{type(self).__name__}: unsupported keyword(s) {sorted(kwargs)} (mmdet's BBoxHead is not "
+                                "available in this environment to take them)")
+            if conv_cfg is not None or norm_cfg is not None:
+                raise NotImplementedError("conv_cfg / norm_cfg need mmcv's ConvModule")
+            nn.Module.__init__(self)
+            self.in_channels, self.num_classes, self.with_avg_pool = in_channels, num_classes, with_avg_pool
+            self.roi_feat_area = roi_feat_size * roi_feat_size
+            if with_avg_pool:
+                self.avg_pool = nn.AvgPool2d(roi_feat_size)
+        assert num_shared_convs + num_shared_fcs + num_cls_convs + num_cls_fcs + num_reg_convs + num_reg_fcs > 0      # :87-88
+        if num_cls_convs > 0 or num_reg_convs > 0:
+            assert num_shared_fcs == 0                                                                                  # :89-90
+        self.num_shared_convs, self.num_shared_fcs = num_shared_convs, num_shared_fcs
+        self.num_cls_convs, self.num_cls_fcs = num_cls_convs, num_cls_fcs
+        self.num_reg_convs, self.num_reg_fcs = num_reg_convs, num_reg_fcs
+        self.conv_out_channels, self.fc_out_channels = conv_out_channels, fc_out_channels
+        self.shared_convs, self.shared_fcs, last = self._add_conv_fc_branch(num_shared_convs, num_shared_fcs, self.in_channels, True)
+        self.shared_out_channels = last
+        self.cls_convs, self.cls_fcs, self.cls_last_dim = self._add_conv_fc_branch(num_cls_convs, num_cls_fcs, last)
+        self.reg_convs, self.reg_fcs, self.reg_last_dim = self._add_conv_fc_branch(num_reg_convs, num_reg_fcs, last)
+        if num_shared_fcs == 0 and not self.with_avg_pool:                                                              # :119-123
+            if num_cls_fcs == 0:
+                self.cls_last_dim *= self.roi_feat_area
+            if num_reg_fcs == 0:
+                self.reg_last_dim *= self.roi_feat_area
+        self.relu = nn.ReLU(inplace=True)
+        self._build_task_predictors(self.cls_last_dim, self.reg_last_dim, num_classes, task_split, task_id, reg_class_agnostic)
+        self.null_space = False
+
+    def _add_conv_fc_branch(self, num_convs: int, num_fcs: int, in_channels: int, is_shared: bool = False):
+        """convs -> avg pool (optional) -> fcs  (convfc_bbox_head_task.py:146-189)."""
+        last = in_channels
+        convs = nn.ModuleList()
+        for i in range(num_convs):
+            convs.append(_ConvReLU(last if i == 0 else self.conv_out_channels, self.conv_out_channels))
+        if num_convs > 0:
+            last = self.conv_out_channels
+        fcs = nn.ModuleList()
+        if num_fcs > 0:
+            if (is_shared or self.num_shared_fcs == 0) and not self.with_avg_pool:
+                last *= self.roi_feat_area
+            for i in range(num_fcs):
+                fcs.append(nn.Linear(last if i == 0 else self.fc_out_channels, self.fc_out_channels))
+            last = self.fc_out_channels
+        return convs, fcs, last
+
+    def get_mid_features(self, x: torch.Tensor) -> torch.Tensor:
+        """What the RoI dump stores: the features after the shared convs, flattened, BEFORE the shared FCs (:290-323)."""
+        for conv in self.shared_convs:
+            x = conv(x)
+        if self.num_shared_fcs > 0 and self.with_avg_pool:
+            x = self.avg_pool(x)
+        return x.flatten(1) if x.dim() > 2 else x
+
+    def _branch(self, x, convs, fcs):
+        for conv in convs:
+            x = conv(x)
+        if x.dim() > 2:
+            if self.with_avg_pool:
+                x = self.avg_pool(x)
+            x = x.flatten(1)
+        for fc in fcs:
             x = self.relu(fc(x))
-        return self._task_predict(x, x)
+        return x
+
+    def forward(self, x):
+        # the prototype bank replays FLATTENED mid features ([K x 12544], head:490-499): convs are skipped for 2-D input
+        if x.dim() > 2:
+            for conv in self.shared_convs:
+                x = conv(x)
+        if self.num_shared_fcs > 0:
+            if x.dim() > 2:
+                if self.with_avg_pool:
+                    x = self.avg_pool(x)
+                x = x.flatten(1)
+            for fc in self.shared_fcs:
+                x = self.relu(fc(x))
+        return self._task_predict(self._branch(x, self.cls_convs, self.cls_fcs), self._branch(x, self.reg_convs, self.reg_fcs))
 
 
-# the reference's general class name resolves to the same implementation for the Shared2FC shape
-register(MODELS, "ConvFCBBoxHeadTask")(Shared2FCBBoxHeadTask)
+@register(MODELS)
+class Shared2FCBBoxHeadTask(ConvFCBBoxHeadTask):
+    """flatten -> (Linear + ReLU) x 2 -> per-task cls || per-task reg: ``ConvFCBBoxHeadTask`` with two shared FCs and nothing
+    else, exactly as the reference defines it (convfc_bbox_head_task.py:516-529)."""
+
+    def __init__(self, fc_out_channels: int = 1024, *args, **kwargs):
+        super().__init__(*args, num_shared_convs=0, num_shared_fcs=2, num_cls_convs=0, num_cls_fcs=0, num_reg_convs=0,
+                         num_reg_fcs=0, fc_out_channels=fc_out_channels, **kwargs)

@@ -90,58 +90,6 @@ def test_detector_modes(N, dev):
         model(x, samples, mode="bogus")
 
 
-def test_graphed_trunk_matches_eager(N, dev):
-    """hipGraph replay of backbone + FPN + RPN convolutions (student fwd/bwd, teacher fwd) gives the eager losses and
-    gradients; parameter names are untouched; eval-mode passes stay eager so covariance hooks still fire."""
-    from nsgp_repre_amd.detection import build_faster_rcnn
-    torch.manual_seed(0)
-    model = build_faster_rcnn(width=16, fc_out_channels=64, task_id=2).to(dev)
-    mix = N.runner.br_nullspace_runner.NullSpaceTaskMixin()
-    mix.task_id = 2
-    mix.attach_teacher(model)
-    model.train()
-    names = [n for n, _ in model.named_parameters()]
-    x, samples = _batches(dev, 1, (15, 20), 0)[0]
-
-    def run():
-        torch.manual_seed(11)                                  # the samplers draw from the default generator
-        model.zero_grad()
-        losses = model(x, copy.deepcopy(samples), mode="loss")
-        sum(v for k, v in losses.items() if "loss" in k).backward()
-        return ({k: v.detach().clone() for k, v in losses.items()},
-                {n: p.grad.detach().clone() for n, p in model.named_parameters() if p.grad is not None})
-
-    l0, g0 = run()
-    model.enable_graphs(x)
-    assert [n for n, _ in model.named_parameters()] == names
-    for _ in range(2):                                          # replay twice: static buffers are reused
-        l1, g1 = run()
-        for k in l0:
-            torch.testing.assert_close(l1[k], l0[k], rtol=1e-4, atol=1e-5)
-        assert set(g1) == set(g0)
-        for n in g0:    # MIOpen's backward-weights kernels accumulate with atomics: eager runs themselves differ by ~0.5 % on the
-            # small-gradient layers, so this is a wiring check (a wrong graph is off by O(1)), not a rounding check
-            assert (g1[n] - g0[n]).norm().item() <= 5e-2 * g0[n].norm().item() + 1e-12, n
-    # a different input shape falls back to the eager path
-    x2, s2 = _batches(dev, 1, (15, 20), 1, h=128, w=160)[0]
-    assert all(torch.isfinite(v) for v in model(x2, s2, mode="loss").values())
-    # eval mode: eager, forward hooks fire
-    fired = []
-    h = model.backbone.layer2[0].conv1.register_forward_hook(lambda m, i, o: fired.append(1))
-    model.eval()
-    with torch.no_grad():
-        model(x, copy.deepcopy(samples), mode="nullspace")
-    h.remove()
-    assert fired
-    # release the graphs here and now, not whenever the garbage collector gets to the cycle make_graphed_callables leaves
-    model.disable_graphs()
-    assert "_graph_train" not in model.__dict__ and "_graph_eval" not in model.teacher_model.__dict__
-    del model
-    import gc
-    gc.collect()
-    torch.cuda.synchronize()
-
-
 def _rel(a, b):
     a, b = a.detach().double(), b.detach().double()
     return ((a - b).abs().max() / b.abs().max().clamp_min(1e-30)).item()
@@ -181,6 +129,12 @@ def test_two_task_cycle_on_the_detector(N, dev):
         feats, cls_t = rois[0], rois[1]
         assert feats.shape == (75, 12544) and sorted(set(cls_t.tolist()) - {20}) == list(range(15))
         assert os.path.exists(os.path.join(w1, "covariance.pth")) and os.path.exists(os.path.join(w1, "rois_etc.pth"))
+        # runner:591, 946-990: task 1 leaves the Fisher diagonal of its BN parameters next to them; runner:295-299: and a checkpoint
+        ewc1 = torch.load(os.path.join(w1, "ewc_reg_terms_ewc.pth"), weights_only=True)
+        bn_names = [n for n, _ in m1.named_parameters() if "bn" in n]
+        assert sorted(ewc1["importance"]) == sorted(bn_names) and all(len(v) == 1 for v in ewc1["task_param"].values())
+        assert sum(float(v[0].sum()) for v in ewc1["importance"].values()) > 0
+        assert os.path.exists(os.path.join(w1, "best_final.pth"))
 
         m2 = build_faster_rcnn(width=16, fc_out_channels=64, task_id=2, task_split=split, previous_path=w1).to(dev)
         m2.load_state_dict(m1.state_dict())
@@ -192,9 +146,21 @@ def test_two_task_cycle_on_the_detector(N, dev):
         body = [p for n, p in m2.named_parameters() if n.startswith(("backbone", "neck"))]
         rest = [p for n, p in m2.named_parameters() if not n.startswith(("backbone", "neck"))]
         o2 = N.SGDNSCL([dict(params=body, lr=0.5), dict(params=rest)], lr=0.002, momentum=0.9, weight_decay=0.0, svd=True)
-        r2 = N.runner.BRNullSpaceRunner(m2, o2, w2, task_id=2, train_task_split=split, previous_dir=w1, ignore_keys=ignore)
+        r2 = N.runner.BRNullSpaceRunner(m2, o2, w2, task_id=2, train_task_split=split, previous_dir=w1, ignore_keys=ignore,
+                                        rr_thresh=[0.5, 0.7])
         r2.train(step_fn, _batches(dev, 2, (15, 20), 4), cov_forward=cov_fwd, cov_batches=_batches(dev, 2, (15, 20), 5))
+        assert (m2.rpn_thresh, m2.roi_thresh) == (0.5, 0.7)                     # runner:439-441
         assert "replay_loss_cls" in step_fn.last and all(torch.isfinite(v) for v in step_fn.last.values())
+        # runner:558-565: the task-2 loss dict carries the EWC term, by the rule of runner:1055-1071 (G6 pins the kernel):
+        # 1000 * sum_n sum(F_n (theta_n - theta*_n)^2) over the BN parameters that require grad.  step_fn.last is the last
+        # forward of the run (the importance pass, on the final weights).
+        assert isinstance(m2.loss, N.runner.ewc.EWCHook) and "ewc_loss" in step_fn.last
+        now = dict(m2.named_parameters())
+        want = sum(1000.0 * (ewc1["importance"][n][0].to(dev).double() * (now[n].detach().double().unsqueeze(0) - ewc1["task_param"][n][0].to(dev).double()) ** 2).sum()
+                   for n in bn_names if now[n].requires_grad)
+        assert float(want) > 0 and abs(float(step_fn.last["ewc_loss"]) - float(want)) <= 1e-4 * float(want)
+        ewc2 = torch.load(os.path.join(w2, "ewc_reg_terms_ewc.pth"), weights_only=True)
+        assert all(len(v) == 2 for v in ewc2["importance"].values())            # task 1's entry + task 2's (runner:985-987)
         assert hasattr(m2, "teacher_model") and m2.teacher_model.roi_head.bbox_head.task_id == 1
         assert not any(p.requires_grad for p in m2.teacher_model.parameters())
         names = set(o2.transforms.keys())

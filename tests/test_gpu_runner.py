@@ -142,8 +142,25 @@ def test_two_task_run_keeps_old_features_fixed(N, dev):
         net = Net().to(dev)
         opt = N.SGDNSCL(net.parameters(), lr=0.05, momentum=0.9, svd=True)
         r1 = N.runner.BRNullSpaceRunner(net, opt, w1, task_id=1, ignore_keys=["rpn", "roi_head"])
-        cov, _ = r1.train(lambda m, b: m(b), data1)
+        seen = {"n": 0}
+
+        def step1(m, b):        # a "best" checkpoint is written after the second step, two more steps follow
+            if seen["n"] == 2:
+                r1.save_checkpoint(m, "best_loss_iter_2.pth")
+                seen["best"] = {k: v.detach().clone() for k, v in m.state_dict().items()}
+            seen["n"] += 1
+            return m(b)
+        cov, _ = r1.train(step1, data1, importance_loss=lambda m, b: m(b))
         assert os.path.exists(os.path.join(w1, "covariance.pth")) and len(opt.transforms) == 0
+        # runner:710-716: the end-of-task passes run on the RELOADED ckpt_keywords checkpoint, not on the last iteration's weights:
+        # the model is back at the saved state, and covariance.pth is the covariance of THAT model (conv2's input depends on conv1 + bn1)
+        for k, v in net.state_dict().items():
+            assert torch.equal(v, seen["best"][k]), k
+        ref = Net()
+        ref.load_state_dict({k: v.cpu() for k, v in seen["best"].items()})
+        want = _oracle_covariances(ref, [d.cpu() for d in data1], N.runner.nullspace.full_ignore_keys(["rpn", "roi_head"]))
+        assert _rel(cov["backbone.conv2.weight"], want["backbone.conv2.weight"]) <= 1e-4
+        assert os.path.exists(os.path.join(w1, "ewc_reg_terms_ewc.pth"))                          # runner:591
         before = {n: p.detach().clone() for n, p in net.named_parameters()}
         opt2 = N.SGDNSCL(net.parameters(), lr=0.05, momentum=0.9, svd=True)
         r2 = N.runner.BRNullSpaceRunner(net, opt2, w2, task_id=2, previous_dir=w1, ignore_keys=["rpn", "roi_head"])

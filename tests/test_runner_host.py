@@ -238,3 +238,86 @@ def test_exchange_steps_are_identity_without_process_group(N):
     assert torch.equal(d["x"], torch.ones(2, 2))
     t = torch.arange(6.0).reshape(3, 2)
     assert len(D.all_gather_different_shape(t)) == 1 and D.get_world_size() == 1 and D.get_rank() == 0
+
+
+def test_task_flow_pieces_of_the_mixin(N):
+    """Host side of the reference's train() additions that need no GPU: rr_thresh wiring (runner:439-441), checkpoints by
+    keyword (runner:295-299, 710-716), the EWC importance pass and its file (runner:946-990)."""
+    class Tiny(nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.conv = nn.Conv2d(2, 3, 1)
+            self.bn1 = nn.BatchNorm2d(3)
+
+        def forward(self, x):
+            return self.bn1(self.conv(x)).square().mean()
+
+    torch.manual_seed(0)
+    with tempfile.TemporaryDirectory() as td:
+        w1, w2 = os.path.join(td, "t_1"), os.path.join(td, "t_2")
+        os.makedirs(w1), os.makedirs(w2)
+        mix = N.runner.br_nullspace_runner.NullSpaceTaskMixin()
+        mix.init_task_state(w1, task_id=1, rr_thresh=[0.5, 0.7], ckpt_keywords="best")
+        net = Tiny()
+        mix.set_pseudo_label_thresholds(net)
+        assert (net.rpn_thresh, net.roi_thresh) == (0.5, 0.7)
+        assert mix.reload_task_checkpoint(net) is None                     # nothing saved yet
+        mix.save_checkpoint(net, "best_x.pth")
+        saved = {k: v.clone() for k, v in net.state_dict().items()}
+        with torch.no_grad():
+            net.conv.weight.add_(1.0)
+        assert mix.reload_task_checkpoint(net).endswith("best_x.pth")
+        assert all(torch.equal(v, saved[k]) for k, v in net.state_dict().items())
+        # importance: F = sum_b grad_b^2 * len(batch)/len(loader), only the "bn" parameters, in eval mode
+        data = [torch.randn(4, 2, 5, 5) for _ in range(3)]
+        terms = mix.calculate_save_importance(net, data, lambda m, b: m(b))
+        assert sorted(terms["importance"]) == ["bn1.bias", "bn1.weight"] and not net.training
+        want = torch.zeros(3)
+        for b in data:
+            net.zero_grad()
+            net(b).backward()
+            want += net.bn1.weight.grad ** 2 * (len(b) / len(data))
+        assert torch.allclose(terms["importance"]["bn1.weight"][0][0], want, rtol=1e-6, atol=1e-12)
+        disk = torch.load(os.path.join(w1, "ewc_reg_terms_ewc.pth"), weights_only=True)
+        assert torch.equal(disk["task_param"]["bn1.bias"][0][0], net.bn1.bias.detach())
+        # the next task finds the previous directory's checkpoint and importance file
+        nxt = N.runner.br_nullspace_runner.NullSpaceTaskMixin()
+        nxt.init_task_state(w2, task_id=2, previous_dir=w1, ckpt_keywords="best")
+        net2 = Tiny()
+        assert nxt.load_previous_checkpoint(net2).endswith("best_x.pth")
+        assert torch.equal(net2.conv.weight, net.conv.weight)
+        assert nxt.rr_thresh == [0.5, 0.5]                                   # runner:356 default
+        loaded = nxt.load_importance(net2)
+        assert sorted(nxt.reg_params) == ["bn1.bias", "bn1.weight"] and len(loaded["importance"]["bn1.weight"]) == 1
+
+
+def test_general_convfc_task_head(N):
+    """``ConvFCBBoxHeadTask`` beyond the Shared2FC shape (convfc_bbox_head_task.py:14-288): shared convs, separate cls / reg
+    conv + fc branches, the reference's layer names and dimension rules, future-task logits at -inf; unknown keywords raise."""
+    H = N.roi_heads.ConvFCBBoxHeadTask
+    head = H(num_shared_convs=1, num_cls_convs=1, num_cls_fcs=1, num_reg_fcs=2, conv_out_channels=6, fc_out_channels=10,
+             in_channels=4, roi_feat_size=3, num_classes=6, task_split=[0, 2, 4, 6], task_id=2)
+    names = [n for n, _ in head.named_parameters()]
+    assert "shared_convs.0.conv.weight" in names and "cls_convs.0.conv.weight" in names and "cls_fcs.0.weight" in names
+    assert "reg_fcs.1.bias" in names and len(head.fc_cls) == 4 and len(head.fc_reg) == 3
+    assert head.cls_fcs[0].in_features == 6 * 9 and head.reg_fcs[0].in_features == 6 * 9 and head.fc_reg[0].out_features == 8
+    # heads of the task that has not arrived are frozen, the background head is not (:130-144)
+    assert [m.weight.requires_grad for m in head.fc_cls] == [True, True, False, True]
+    assert [m.weight.requires_grad for m in head.fc_reg] == [True, True, False]
+    x = torch.randn(5, 4, 3, 3)
+    cls, reg = head(x)
+    assert cls.shape == (5, 7) and reg.shape == (5, 24)
+    assert torch.isinf(cls[:, 4:6]).all() and (cls[:, 4:6] < 0).all() and torch.isfinite(cls[:, :4]).all() and torch.isfinite(cls[:, 6]).all()
+    assert (reg[:, 16:] == 0).all()
+    assert head.get_mid_features(x).shape == (5, 6 * 9)
+    # no fcs in a branch: its predictor sees the flattened map (:119-123)
+    h2 = H(num_shared_convs=1, conv_out_channels=6, in_channels=4, roi_feat_size=3, num_classes=4, task_split=[0, 2, 4], task_id=1)
+    assert h2.fc_cls[0].in_features == 6 * 9 and h2(x)[0].shape == (5, 5)
+    with pytest.raises(AssertionError):
+        H(num_cls_convs=1, num_shared_fcs=1)                           # :89-90
+    with pytest.raises(AssertionError):
+        H()                                                            # :87-88
+    with pytest.raises(TypeError):
+        H(num_shared_fcs=1, loss_clz=dict(type="CrossEntropyLoss"))    # unknown keyword: not swallowed
+    s2 = N.roi_heads.Shared2FCBBoxHeadTask(in_channels=4, fc_out_channels=8, roi_feat_size=3, num_classes=4, task_split=[0, 2, 4], task_id=2)
+    assert isinstance(s2, H) and [n for n, _ in s2.named_parameters()][:2] == ["shared_fcs.0.weight", "shared_fcs.0.bias"]
