@@ -39,9 +39,10 @@ constexpr int V2_NB = 2;                                // column blocks of a ti
 constexpr int V2_MB_MAX = 4;                            // row blocks of a full tile (256 rows)
 constexpr int V2_STAGE = (V2_MB_MAX + V2_NB) * V2_STEP; // 48 KiB
 constexpr int V2_STAGES = 3;
-constexpr int V2_SMEM_BYTES = V2_STAGES * V2_STAGE;     // 147,456 B
+constexpr int V2_RING_BYTES = V2_STAGES * V2_STAGE;     // 147,456 B
+constexpr int V2_SMEM_BYTES = V2_RING_BYTES + 512;      // + the landing pad of the L2-prefetch touches (2 waves x 256 B)
 constexpr int V2_THREADS = 512;
-static_assert(8 * 64 * EPI_LD * 4 <= V2_SMEM_BYTES, "the epilogue re-layout (16 KiB per wave) must fit the ring");
+static_assert(8 * 64 * EPI_LD * 4 <= V2_RING_BYTES, "the epilogue re-layout (16 KiB per wave) must fit the ring");
 
 typedef __attribute__((address_space(3))) char lds_char;
 
@@ -53,12 +54,13 @@ __host__ __device__ __forceinline__ size_t v2_operand_bytes(int rows, int K) { r
 
 template <int N>
 __device__ __forceinline__ void v2_wait_vmcnt() {
+    static_assert(N >= 0 && N <= 8, "vmcnt immediates used by the ring");
     if constexpr (N == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    else if constexpr (N == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
     else if constexpr (N == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-    else {
-        static_assert(N == 6, "counts: 0, 4 (MB = 2), 6 (MB = 4)");
-        asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-    }
+    else if constexpr (N == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    else if constexpr (N == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else static_assert(N == 0, "unused count");
 }
 
 // raw barrier (a __syncthreads() would drain the LDS-DMA prefetch with vmcnt(0)); the empty asms keep the compiler from
@@ -112,12 +114,16 @@ __device__ __forceinline__ void v2_dma_group(const unsigned long long (&src)[V2_
 // acc += A[rows of blocks a_block0 .. +MB) x B[cols of blocks b_block0, b_block0 + 1), both pre-tiled / pre-split with K
 // columns (K % 32 == 0).  512 threads.  On return every wave has passed a barrier after its last LDS read and no DMA is
 // in flight: the ring is free for the caller's epilogue.
-// Study knobs (tools/proj_v2_bench.hip; profiles/r02/proj_v2_schedule_study.log), defaults = what measured best at
-// sustained clocks:  STAGGER -- the two waves that share a SIMD (w and w + 4) issue their DMA pieces at different points of
-// the step (waves 4-7 between the two k16 halves): -5 %.  PATTERN -- the LDS-read / MFMA interleave pinned with
-// sched_group_barriers: 0 = 8 reads, (MFMA, read) x 8, 16 MFMAs; 1 = all 16 reads first; 2 = the compiler's own; 3 = 4 reads,
-// (MFMA, read) x 12: all within 2 %.  (The v_mfma_f32_16x16x32_f16 form of the same step measured the same 415 TF-eq.)
-template <int MB, bool STAGGER = false, int PATTERN = 0>
+// Measured and not kept (tools/proj_v2_bench.hip at its round-2 commits; profiles/r02/proj_v2_schedule_study.log): staggering the
+// DMA issue of the two waves that share a SIMD (-5 % at sustained clocks); other LDS-read / MFMA interleaves (all reads first, the
+// compiler's own order, 4 reads then one per MFMA: within 2 %); the v_mfma_f32_16x16x32_f16 form of the step (the same 415 TF-eq).
+// PF > 0: L2 PREFETCH of the projector stream.  The pre-split projector is the one operand that comes from HBM (0.58 GB per
+// step for R-50-FPN, read once); a DMA piece issued two steps (~2.4 us) ahead just about covers an HBM round trip under load.
+// Waves 0 and 1 therefore also "touch" the B planes of step t + PF -- one global_load_lds_dword per wave and step, 64 lanes x
+// 128-byte stride = one 4-byte read from every cache line of an 8 KiB block-step, landing in 256 B of scratch LDS behind the
+// ring -- so that the DMA proper finds its lines in the XCD's L2.  The touches ride in the same in-order vmcnt queue: a
+// touching wave has two more operations outstanding (counts 8 / 2 instead of 6 / 0).
+template <int MB, int PF = 0>
 __device__ __forceinline__ void gemm_tile_f16x2_v2(const void* __restrict__ Asplit, int a_block0, const void* __restrict__ Bsplit,
                                                    int b_block0, int K, char* smem, f32x16 (&acc)[2][2]) {
     static_assert(MB == 2 || MB == 4, "MB");
@@ -143,6 +149,17 @@ __device__ __forceinline__ void gemm_tile_f16x2_v2(const void* __restrict__ Aspl
 #pragma unroll
         for (int b = 0; b < V2_MB_MAX + V2_NB; ++b) src[b] += V2_STEP;
     };
+    // touch (waves 0, 1; wave w covers column block w): every line of B block w's planes of step `ts`, clamped to the last step
+    const unsigned long long touch_base = v2_uniform((unsigned long long)(uintptr_t)Bsplit + (size_t)(b_block0 + (wave & 1)) * blk);
+    const unsigned touch_voff = lane * 128;
+    const unsigned touch_lds = __builtin_amdgcn_readfirstlane(lds_base + V2_RING_BYTES + (wave & 1) * 256);
+    auto touch = [&](int ts) {
+        const unsigned long long srcp = touch_base + (size_t)(ts < nk ? ts : nk - 1) * V2_STEP;
+        unsigned keep;
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %1, %3\n\ts_mov_b32 m0, %0"
+                     : "=&s"(keep)
+                     : "v"(touch_voff), "s"(touch_lds), "s"(srcp));
+    };
     // per-lane read offsets inside a stage: lanes 0-31 take octet 2ks, lanes 32-63 octet 2ks + 1 of their row
     const int r = lane & 31, h = lane >> 5;
     const lds_char* abase = (const lds_char*)smem + wm * V2_STEP + h * (2 * V2_PLANE) + r * 16;
@@ -152,13 +169,9 @@ __device__ __forceinline__ void gemm_tile_f16x2_v2(const void* __restrict__ Aspl
     // One step = 16 ds_read_b128 (two k16 halves x {a0, a1, b0, b1} x two 32-row blocks) + 24 MFMAs.  The schedule is pinned
     // with sched_group_barriers: four reads, then one read behind each of the next twelve MFMAs, then the remaining MFMAs --
     // left alone, hipcc issues 4 reads, waits, 4 MFMAs, ... with the matrix pipe idle during every wait.
-    auto compute = [&](auto st, auto st_dma, auto late_dma) {
-        constexpr int ST = decltype(st)::value, SD = decltype(st_dma)::value;
-        constexpr bool LATE = decltype(late_dma)::value != 0;        // issue this step's DMA between the k16 halves
-        if (!active) {
-            if (LATE) issue(SD);
-            return;
-        }
+    auto compute = [&](auto st) {
+        constexpr int ST = decltype(st)::value;
+        if (!active) return;
         h16x8 fa[2][2][2], fb[2][2][2];     // [k16 half][32-row block][term]
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks)
@@ -169,7 +182,8 @@ __device__ __forceinline__ void gemm_tile_f16x2_v2(const void* __restrict__ Aspl
                     fa[ks][i][p] = *reinterpret_cast<lds_frag>(abase + ST * V2_STAGE + ks * (4 * V2_PLANE) + p * V2_PLANE + i * 512);
                     fb[ks][i][p] = *reinterpret_cast<lds_frag>(bbase + ST * V2_STAGE + ks * (4 * V2_PLANE) + p * V2_PLANE + i * 512);
                 }
-        auto half = [&](int ks) {           // smallest terms first; consecutive MFMAs belong to four independent accumulator chains
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {    // smallest terms first; consecutive MFMAs belong to four independent accumulator chains
 #pragma unroll
             for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
@@ -182,78 +196,44 @@ __device__ __forceinline__ void gemm_tile_f16x2_v2(const void* __restrict__ Aspl
             for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
                 for (int ni = 0; ni < 2; ++ni) acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[ks][mi][0], fb[ks][ni][0], acc[mi][ni], 0, 0, 0);
-        };
-        half(0);
-        if (LATE) {     // region 1: all 16 reads + the first k16 half's MFMAs; the DMA group; region 2: the second half's MFMAs
-            if (PATTERN == 0) {
-                __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);
-#pragma unroll
-                for (int i = 0; i < 8; ++i) {
-                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-                }
-                __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
-            } else if (PATTERN == 1) {
-                __builtin_amdgcn_sched_group_barrier(0x100, 16, 0);
-                __builtin_amdgcn_sched_group_barrier(0x008, 12, 0);
-            } else if (PATTERN == 3) {
-                __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
-#pragma unroll
-                for (int i = 0; i < 12; ++i) {
-                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-                }
-            }
-            __builtin_amdgcn_sched_barrier(0);
-            issue(SD);
-            __builtin_amdgcn_sched_barrier(0);
-            half(1);
-        } else {
-            half(1);
-            if (PATTERN == 0) {             // 8 reads, one read behind each of the next 8 MFMAs, the other 16 MFMAs
-                __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);
-#pragma unroll
-                for (int i = 0; i < 8; ++i) {
-                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-                }
-                __builtin_amdgcn_sched_group_barrier(0x008, 16, 0);
-            } else if (PATTERN == 1) {
-                __builtin_amdgcn_sched_group_barrier(0x100, 16, 0);
-                __builtin_amdgcn_sched_group_barrier(0x008, 24, 0);
-            } else if (PATTERN == 3) {
-                __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
-#pragma unroll
-                for (int i = 0; i < 12; ++i) {
-                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-                }
-                __builtin_amdgcn_sched_group_barrier(0x008, 12, 0);
-            }
         }
+        __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);        // 8 DS reads (first k16 half)
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);    // 1 MFMA
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);    // 1 DS read (second half)
+        }
+        __builtin_amdgcn_sched_group_barrier(0x008, 16, 0);       // the rest
     };
-    // step t reads stage t % 3; the DMA of step t + 2 goes into stage (t + 2) % 3 = the one step t - 1 read
-    auto step = [&](int t, auto st, auto st_next2, auto late) {
-        constexpr bool LATE = decltype(late)::value != 0;
-        if (t + 1 < nk) v2_wait_vmcnt<NBLK>(); else v2_wait_vmcnt<0>();
+    // step t reads stage t % 3; the DMA of step t + 2 goes into stage (t + 2) % 3 = the one step t - 1 read.
+    // vmcnt at the top of step t: everything OLDER than this wave's own pieces of step t + 1 must have landed.  A touching
+    // wave issues [pieces, touch] per step, so two touches are younger than the pieces of step t (8 / 2 instead of 6 / 0).
+    auto step = [&](int t, auto st, auto st_next2, auto touching) {
+        constexpr int X = decltype(touching)::value ? 2 : 0;
+        if (t + 1 < nk) v2_wait_vmcnt<NBLK + X>(); else v2_wait_vmcnt<X>();
         v2_barrier();
-        const bool dma = t + 2 < nk;
-        if (dma && !LATE) issue(decltype(st_next2)::value);
-        if (dma && LATE) compute(st, st_next2, IC<1>{}); else compute(st, st_next2, IC<0>{});
+        if (t + 2 < nk) issue(decltype(st_next2)::value);
+        if (X) touch(t + PF);
+        compute(st);
     };
-    auto run = [&](auto late) {
+    auto run = [&](auto touching) {
         int t = 0;
         for (; t + 2 < nk; t += 3) {
-            step(t, IC<0>{}, IC<2>{}, late);
-            step(t + 1, IC<1>{}, IC<0>{}, late);
-            step(t + 2, IC<2>{}, IC<1>{}, late);
+            step(t, IC<0>{}, IC<2>{}, touching);
+            step(t + 1, IC<1>{}, IC<0>{}, touching);
+            step(t + 2, IC<2>{}, IC<1>{}, touching);
         }
-        if (t < nk) { step(t, IC<0>{}, IC<2>{}, late); ++t; }
-        if (t < nk) { step(t, IC<1>{}, IC<0>{}, late); ++t; }
+        if (t < nk) { step(t, IC<0>{}, IC<2>{}, touching); ++t; }
+        if (t < nk) { step(t, IC<1>{}, IC<0>{}, touching); ++t; }
     };
+    const bool toucher = PF > 0 && wave < 2;
     issue(0);
-    if (nk > 1) issue(1);
-    if (STAGGER && wave >= 4) run(IC<1>{}); else run(IC<0>{});
+    if (toucher) touch(2);             // keeps the count uniform from step 0 on: [pieces(0), touch, pieces(1), touch]
+    if (nk > 1) {
+        issue(1);
+        if (toucher) touch(3);
+    }
+    if (toucher) run(IC<1>{}); else run(IC<0>{});
     v2_barrier();                      // everybody is done reading: the ring is the caller's
 }
 

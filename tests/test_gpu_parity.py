@@ -185,8 +185,8 @@ def test_g1b_aligned_goldens_per_row(N, dev, golden_dir, kind, split):
 @pytest.mark.parametrize("kind", ["sgd", "adam"])
 def test_g1_eigens_and_transforms_pipeline(N, dev, golden_dir, kind):
     """get_eigens (eigh on the GPU) -> adaptive_threshold -> HIP projector vs the reference's
-    torch.svd route.  Ranks are integers and must match; P is compared at 1e-4 of max|P|
-    (two different eigensolvers on a spectrum spanning 6 decades)."""
+    torch.svd route.  Ranks are integers and must match; P within 1e-5 of max|P| (two fp32 eigensolvers on a spectrum
+    spanning 6 decades; each is within ~4e-6 of the fp64 projector, test_eigensolver_distance_...)."""
     g = np.load(os.path.join(golden_dir, f"g1_{kind}.npz"))
     names, _ = I.g1_layers()
     params = [torch.nn.Parameter(torch.from_numpy(a).to(dev)) for a in I.g1_params()]
@@ -204,7 +204,50 @@ def test_g1_eigens_and_transforms_pipeline(N, dev, golden_dir, kind):
         # rank = trace of the un-normalised projector; recover it from the golden for the check
         P = opt.transforms[n].cpu().numpy()
         assert P.shape == Pref.shape
-        assert np.abs(P - Pref).max() <= 1e-4 * np.abs(Pref).max(), n
+        assert np.abs(P - Pref).max() <= REL * np.abs(Pref).max(), n
+
+
+@pytest.mark.parametrize("kind,gname", [("sgd", "g1_sgd.npz"), ("adam", "g1_adam.npz"), ("sgd", "g1b_sgd.npz")])
+def test_eigensolver_distance_is_the_references_own_conditioning(N, dev, golden_dir, kind, gname):
+    """a5: the product's projector (rocSOLVER ``eigh`` in fp32 -> elbow -> HIP SYRK) differs from the
+    reference's (LAPACK ``gesdd`` in fp32 via torch.svd) by up to 1e-4 of max|P|.  Both are fp32 decompositions of a matrix
+    whose spectrum spans six decades; judged against an fp64 decomposition of the SAME covariance (the projector on the exact
+    null space at the same rank), product and reference are BOTH within 1e-5 of max|P| on every layer (measured 1-4e-6 and
+    0.7-2.4e-6; round 1's 1e-4 allowance was never needed -- the elbow sits at the head of the spectrum, where the gap to the
+    tail makes the projector well conditioned).  Ranks (integers) are equal on every layer, from the product's spectrum, the
+    reference's and the fp64 one."""
+    from nsgp_repre_amd.optim.threshold import elbow_index
+    g = np.load(os.path.join(golden_dir, gname))
+    aligned = gname.startswith("g1b")
+    names, _ = I.g1b_layers() if aligned else I.g1_layers()
+    params = [torch.nn.Parameter(torch.from_numpy(a).to(dev)) for a in (I.g1b_params() if aligned else I.g1_params())]
+    opt = _make_opt(N, kind, params)
+    opt.param_groups[0]["names"] = list(names)
+    covs = I.g1b_covariances() if aligned else I.g1_covariances()
+    opt.get_eigens({n: torch.from_numpy(c).to(dev) for n, c in covs.items()})
+    opt.get_transforms(offset=I.G1_OFFSET)
+    rule = "sgd" if kind == "sgd" else "adam"
+    worst = []
+    for n in (I.g1b_projected() if aligned else I.g1_projected()):
+        C64 = torch.from_numpy(covs[n]).double().to(dev)
+        lam, Q = torch.linalg.eigh(C64)
+        sv64 = lam.abs().flip(0)
+        V64 = Q.flip(1)
+        first = int(elbow_index(opt.eigens[n]["eigen_value"].cpu().numpy(), I.G1_OFFSET, rule))
+        assert first == int(elbow_index(g[f"sigma__{_key(n)}"], I.G1_OFFSET, rule)) == int(elbow_index(sv64.float().cpu().numpy(), I.G1_OFFSET, rule)), n
+        P64 = V64[:, first:] @ V64[:, first:].t()
+        if kind == "adam" or "backbone" in n:
+            P64 = P64 / P64.norm()
+        ours = (opt.transforms[n].double() - P64).abs().max().item() / P64.abs().max().item()
+        ref = (torch.from_numpy(g[f"P__{_key(n)}"]).to(dev).double() - P64).abs().max().item() / P64.abs().max().item()
+        worst.append((n, ours, ref))
+        assert ours <= REL and ref <= REL, (n, ours, ref)          # both fp32 solvers sit inside the 1e-5 gate around the fp64 projector
+    out_dir = os.environ.get("NSGP_REPORT_DIR")
+    if out_dir:
+        import json
+        os.makedirs(out_dir, exist_ok=True)
+        json.dump([dict(layer=n, product_vs_fp64=o, reference_vs_fp64=r) for n, o, r in worst],
+                  open(os.path.join(out_dir, f"eigensolver_vs_fp64_{gname[:-4]}_{kind}.json"), "w"), indent=1)
 
 
 def test_sgdna_pipeline_on_a_gapped_spectrum(N, dev):
@@ -282,6 +325,74 @@ def test_covariance_vs_oracle_mid_sizes(N, dev, cin, k, s, p, hw, B, mode):
             assert torch.isfinite(c2).all() and _rel(c2, ref * f * f) <= REL
     finally:
         ops.cov_set_split_mfma(prev)
+
+
+_TRUE_SIZE = {   # (cin, kernel, stride, pad, H, W) at an 800 x 1344 padded image (bench.py r50_fpn_hooked_convs)
+    "backbone.conv1": (3, 7, 2, 3, 800, 1344),            # L = 268,800 (the longest contraction), D = 147 (ragged)
+    "neck.fpn_convs.0.conv": (256, 3, 1, 1, 200, 336),    # L = 67,200, D = 2304: 713 GFLOP, the largest SYRK
+    "backbone.layer4.0.conv2": (512, 3, 2, 1, 50, 84),    # L = 1,050, D = 4608: the widest covariance
+}
+_cov_true = {}
+
+
+@pytest.mark.parametrize("mode", [0, 2])
+@pytest.mark.parametrize("name", list(_TRUE_SIZE))
+def test_covariance_at_true_size(N, dev, name, mode):
+    """full-size covariance parity was unpinned (tests stopped at 64 x 96 inputs; the 7 x 7 stem differed from
+    rocBLAS by 1.78e-5 with nobody knowing which side was off).  Three R-50-FPN layers at 800 x 1344, both matrix-core paths
+    (0 = fp32 MFMA, 2 = two-term fp16 split), channels spanning three decades, against (i) an fp64 product of the materialised
+    unfold on the GPU -- tensor-max and PER ROW -- and (ii) the ORACLE (the reference's fp32 unfold + mm on the CPU), whose own
+    distance from fp64 is measured beside ours; the adaptive elbow (an INTEGER that decides the projector's rank) must be
+    the same for the fp32 and the fp16-split covariance.  NSGP_REPORT_DIR collects the numbers (profiles/r02/covariance_true_size.json)."""
+    import json
+    import torch.nn.functional as F
+    from nsgp_repre_amd import ops
+    from nsgp_repre_amd.optim.threshold import elbow_index
+    cin, k, st, pd, H, W = _TRUE_SIZE[name]
+    g = torch.Generator().manual_seed(cin + k)
+    x = torch.randn(1, cin, H, W, generator=g).abs() * torch.pow(10.0, -3.0 * (torch.arange(cin) % 8) / 7.0).view(1, cin, 1, 1)
+    xd = x.to(dev)
+    prev = ops.cov_set_split_mfma(mode)
+    try:
+        cov = ops.cov_accumulate_conv2d(xd, (k, k), (st, st), (pd, pd))
+    finally:
+        ops.cov_set_split_mfma(prev)
+    X64 = F.unfold(xd.double(), k, padding=pd, stride=st)[0].t().contiguous()        # [L x D] fp64
+    ref64 = X64.t() @ X64
+    del X64
+    key = (name, "ref")
+    if key not in _cov_true:
+        _cov_true[key] = O.cov_conv2d(x, (k, k), (st, st), (pd, pd))                   # the oracle, once per layer
+    orc = _cov_true[key].to(dev)
+    rec = dict(layer=name, path={0: "f32", 2: "f16x2"}[mode], L=int((H + 2 * pd - k) // st + 1) * int((W + 2 * pd - k) // st + 1), D=cin * k * k,
+               ours_vs_fp64_tensor_rel=_rel(cov, ref64), ours_vs_fp64_row_rel=_row_rel(cov, ref64),
+               oracle_vs_fp64_tensor_rel=_rel(orc, ref64), oracle_vs_fp64_row_rel=_row_rel(orc, ref64),
+               ours_vs_oracle_tensor_rel=_rel(cov, orc), ours_vs_oracle_row_rel=_row_rel(cov, orc))
+    assert torch.equal(cov, cov.t().contiguous())
+    assert rec["ours_vs_fp64_tensor_rel"] <= REL and rec["ours_vs_fp64_row_rel"] <= REL, rec
+    assert rec["ours_vs_oracle_row_rel"] <= REL + rec["oracle_vs_fp64_row_rel"], rec    # the oracle's own fp32 error is not ours to carry
+    # the rank decision (an integer from an argmax over smoothed second differences of the spectrum): the same elbow from this
+    # path's covariance as from the fp64 one -- wherever that argmax is decidable at fp32 precision at all, i.e. wherever
+    # relative perturbations of 2e-6 (the level at which the ORACLE's own fp32 covariance differs from fp64) do not move the
+    # fp64 elbow itself; where they do, two neighbouring indices tie and either is what the reference's fp32 path may produce
+    sv = torch.linalg.eigvalsh(cov.double()).abs().flip(0).float().cpu().numpy()
+    sv64d = torch.linalg.eigvalsh(ref64).abs().flip(0).cpu().numpy()
+    sv_orc = torch.linalg.eigvalsh(orc.double()).abs().flip(0).float().cpu().numpy()
+    e64 = int(elbow_index(sv64d.astype(np.float32), 0.0, "sgd"))
+    rs = np.random.default_rng(5)
+    wobble = {int(elbow_index((sv64d * (1 + 2e-6 * rs.standard_normal(sv64d.shape))).astype(np.float32), 0.0, "sgd")) for _ in range(16)}
+    rec.update(elbow=int(elbow_index(sv, 0.0, "sgd")), elbow_fp64=e64, elbow_oracle=int(elbow_index(sv_orc, 0.0, "sgd")),
+               elbow_fp64_under_2e6_perturbation=sorted(wobble | {e64}))
+    if wobble <= {e64}:
+        assert rec["elbow"] == e64, rec
+    else:
+        assert rec["elbow"] in (wobble | {e64}), rec
+    out_dir = os.environ.get("NSGP_REPORT_DIR")
+    if out_dir:
+        os.makedirs(out_dir, exist_ok=True)
+        f = os.path.join(out_dir, "covariance_true_size.json")
+        rows = json.load(open(f)) if os.path.exists(f) else []
+        json.dump([r for r in rows if (r["layer"], r["path"]) != (rec["layer"], rec["path"])] + [rec], open(f, "w"), indent=1)
 
 
 # ------------------------------------------------------------------ a15 prototypes
@@ -759,6 +870,67 @@ def test_coco_40_40_sized_bank_vs_oracle(N, dev):
         for a, b in zip(masks[c], masks_ref[c]):
             assert torch.equal(a, b), c
     assert _rel(bank, bank_ref) <= REL
+
+
+def test_coco_scale_class_3000_rois_vs_oracle(N, dev):
+    """configs[3]/[4]: one COCO-sized class at the true feature width, N_c = 3000 x 12544 (226 GFLOP of similarity): counts and
+    the bit matrix against the oracle (bit-exact wherever no similarity sits within 1e-5 of the threshold, checked in fp64), the
+    greedy cover's masks / centres and the prototypes themselves."""
+    from nsgp_repre_amd import ops
+    from nsgp_repre_amd.roi_heads.prototype_bank import select_class_prototypes
+    n, d = 3000, 12544
+    Fc = torch.from_numpy(I.class_rois(n, d, 77, n_clusters=5))
+    Fd = Fc.to(dev)
+    n64 = Fd.double() / Fd.double().norm(dim=-1, keepdim=True)
+    sim64 = n64 @ n64.t()
+    ambiguous = ((sim64 - 0.6).abs() < 1e-5).cpu()
+    counts, bitmask = ops.sim_counts(Fd, 0.6)
+    words = bitmask.cpu().numpy().view(np.uint64)
+    got = torch.from_numpy(np.unpackbits(words.view(np.uint8).reshape(n, -1), axis=1, bitorder="little")[:, :n].astype(bool))
+    nrm = Fc / Fc.norm(dim=-1, keepdim=True)
+    ref = (nrm @ nrm.t()) >= 0.6                                   # the oracle's arithmetic (torch CPU fp32)
+    assert torch.equal(got | ambiguous, ref | ambiguous)
+    assert torch.equal(got, got.t())
+    assert torch.equal(counts.cpu(), got.long().sum(-1))           # counts = popcounts of the rows
+    if not bool(ambiguous.any()):
+        co, fine, masks, cen, _ = O.prototype_select(Fc, 10)
+        co2, fine2, masks2, cen2 = select_class_prototypes(Fd, 10)
+        assert cen == cen2 and len(masks) == len(masks2) and all(torch.equal(a, b) for a, b in zip(masks, masks2))
+        assert _rel(co2, co) <= REL and all(_rel(a, b) <= REL for a, b in zip(fine2, fine))
+
+
+def test_coco_stress_class_20000_rois_properties(N, dev):
+    """configs[4]'s "large prototype bank": N_c = 20,000 x 12544 (1 GB of features, 10 TFLOP of similarity, a 50 MB bit
+    matrix instead of the reference's 1.6 GB fp32 + 3.2 GB int64).  No CPU oracle at this size: size-independent properties --
+    the bit matrix is symmetric with a set diagonal, counts are the row popcounts, sampled entries agree with an fp64
+    similarity, every fine prototype is the mean of the rows its mask selects, and the build is bitwise repeatable."""
+    from nsgp_repre_amd import ops
+    from nsgp_repre_amd.roi_heads.prototype_bank import select_class_prototypes
+    n, d = 20000, 12544
+    g = torch.Generator(device=dev).manual_seed(3)
+    centres = torch.relu(torch.randn(6, d, device=dev, generator=g))
+    which = torch.randint(0, 6, (n,), device=dev, generator=g)
+    F = torch.empty(n, d, device=dev)
+    for lo in range(0, n, 2500):
+        F[lo:lo + 2500] = torch.relu(centres[which[lo:lo + 2500]] + 0.6 * torch.randn(2500, d, device=dev, generator=g))
+    counts, bitmask = ops.sim_counts(F, 0.6)
+    words = bitmask.cpu().numpy().view(np.uint64)
+    bits = np.unpackbits(words.view(np.uint8).reshape(n, -1), axis=1, bitorder="little")[:, :n].astype(bool)
+    assert np.array_equal(bits, bits.T) and bits.diagonal().all()
+    assert np.array_equal(counts.cpu().numpy(), bits.sum(1))
+    rs = np.random.default_rng(0)
+    ii, jj = rs.integers(0, n, 4000), rs.integers(0, n, 4000)
+    Fi, Fj = F[torch.from_numpy(ii).to(dev)].double(), F[torch.from_numpy(jj).to(dev)].double()
+    s64 = ((Fi * Fj).sum(1) / (Fi.norm(dim=1) * Fj.norm(dim=1))).cpu().numpy()
+    clear = np.abs(s64 - 0.6) > 1e-5
+    assert np.array_equal(bits[ii, jj][clear], (s64 >= 0.6)[clear])
+    co, fine, masks, cen = select_class_prototypes(F, 10)
+    assert 1 <= len(fine) <= 9 and len(set(cen)) == len(cen)
+    assert _rel(co, F.double().mean(0, keepdim=True)) <= REL
+    for f, m in zip(fine, masks):
+        assert _rel(f, F[m.to(dev)].double().mean(0, keepdim=True)) <= REL
+    co2, fine2, masks2, cen2 = select_class_prototypes(F, 10)
+    assert cen2 == cen and torch.equal(co2, co) and all(torch.equal(a, b) for a, b in zip(fine2, fine))
 
 
 def test_step_is_bitwise_deterministic(N, dev):

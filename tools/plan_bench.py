@@ -30,17 +30,21 @@ def run(layers, label, steps=12):
     fl, by, tiles, nl = opt.plan_stats()
     print(f"{label:34s} tiles {tiles:5d}  update {u*1e3:7.1f} us  gemm {g*1e3:8.1f} us  {fl/g/1e9:6.1f} TF", flush=True)
 
-run([(4096, 4096)], "1x(4096,4096) = 1024 tiles")
-run([(512, 4096)] * 8, "8x(512,4096) = 1024 tiles")
-run([(512, 4608)] * 3, "3x(512,4608) = 432 tiles")
-run([(2048, 1024)] * 8, "8x(2048,1024) = 1024 tiles")
-run([(256, 2304)] * 10, "10x(256,2304) = 360 tiles")
-run([(1024, 256)] * 64, "64x(1024,256) = 1024 tiles")
+run([(4096, 4096)], "1x(4096,4096)")
+run([(512, 4608)] * 3, "3x(512,4608)")
+run([(256, 2304)] * 10, "10x(256,2304)")
+run([(256, 2304)] * 27, "27x(256,2304)")
+run([(256, 1024)] * 23, "23x(256,1024)")
+run([(1024, 256)] * 23, "23x(1024,256)")
+run([(1024, 256)] * 64, "64x(1024,256)")
+run([(2048, 1024)] * 8, "8x(2048,1024)")
 r50 = [(c, d) for _, c, d in O.resnet_fpn_projected_layers(50)]
 run(r50, "R-50-FPN table")
-run(sorted(r50, key=lambda x: x[1]), "R-50-FPN table (listed small-K first)")
 r101 = [(c, d) for _, c, d in O.resnet_fpn_projected_layers(101)]
 run(r101, "R-101-FPN table")
+run([x for x in r101 if x[1] >= 1024], "R-101 layers with D >= 1024")
+run([x for x in r101 if x[1] < 1024], "R-101 layers with D < 1024")
+sys.exit(0)
 
 # --- the single-launch API on one big problem (same kernel body, 2-D grid, pointers as kernel args)
 from nsgp_repre_amd import ops
