@@ -40,7 +40,7 @@ constexpr int V2_MB_MAX = 4;                            // row blocks of a full 
 constexpr int V2_STAGE = (V2_MB_MAX + V2_NB) * V2_STEP; // 48 KiB
 constexpr int V2_STAGES = 3;
 constexpr int V2_RING_BYTES = V2_STAGES * V2_STAGE;     // 147,456 B
-constexpr int V2_SMEM_BYTES = V2_RING_BYTES + 512;      // + the landing pad of the L2-prefetch touches (2 waves x 256 B)
+constexpr int V2_SMEM_BYTES = V2_RING_BYTES;
 constexpr int V2_THREADS = 512;
 static_assert(8 * 64 * EPI_LD * 4 <= V2_RING_BYTES, "the epilogue re-layout (16 KiB per wave) must fit the ring");
 
@@ -54,13 +54,10 @@ __host__ __device__ __forceinline__ size_t v2_operand_bytes(int rows, int K) { r
 
 template <int N>
 __device__ __forceinline__ void v2_wait_vmcnt() {
-    static_assert(N >= 0 && N <= 8, "vmcnt immediates used by the ring");
+    static_assert(N == 0 || N == 4 || N == 6, "counts: 0, 4 (MB = 2), 6 (MB = 4)");
     if constexpr (N == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    else if constexpr (N == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
     else if constexpr (N == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-    else if constexpr (N == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-    else if constexpr (N == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-    else static_assert(N == 0, "unused count");
+    else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
 }
 
 // raw barrier (a __syncthreads() would drain the LDS-DMA prefetch with vmcnt(0)); the empty asms keep the compiler from
@@ -117,13 +114,11 @@ __device__ __forceinline__ void v2_dma_group(const unsigned long long (&src)[V2_
 // Measured and not kept (tools/proj_v2_bench.hip at its round-2 commits; profiles/r02/proj_v2_schedule_study.log): staggering the
 // DMA issue of the two waves that share a SIMD (-5 % at sustained clocks); other LDS-read / MFMA interleaves (all reads first, the
 // compiler's own order, 4 reads then one per MFMA: within 2 %); the v_mfma_f32_16x16x32_f16 form of the step (the same 415 TF-eq).
-// PF > 0: L2 PREFETCH of the projector stream.  The pre-split projector is the one operand that comes from HBM (0.58 GB per
-// step for R-50-FPN, read once); a DMA piece issued two steps (~2.4 us) ahead just about covers an HBM round trip under load.
-// Waves 0 and 1 therefore also "touch" the B planes of step t + PF -- one global_load_lds_dword per wave and step, 64 lanes x
-// 128-byte stride = one 4-byte read from every cache line of an 8 KiB block-step, landing in 256 B of scratch LDS behind the
-// ring -- so that the DMA proper finds its lines in the XCD's L2.  The touches ride in the same in-order vmcnt queue: a
-// touching wave has two more operations outstanding (counts 8 / 2 instead of 6 / 0).
-template <int MB, int PF = 0>
+// Also measured and not kept (profiles/r02/proj_v2_prefetch_study.log): an L2 prefetch of the projector stream (the one operand
+// that comes from HBM) by 4-byte "touch" loads 3-12 steps ahead -- with the projector rotated through 700 MB of copies so that
+// every launch streams it from HBM, the kernel runs at the SAME rate as with a cache-resident projector (410 vs 380-400 TF-eq)
+// and the touches cost 2.5 %: two steps of DMA prefetch already cover the HBM round trip.
+template <int MB>
 __device__ __forceinline__ void gemm_tile_f16x2_v2(const void* __restrict__ Asplit, int a_block0, const void* __restrict__ Bsplit,
                                                    int b_block0, int K, char* smem, f32x16 (&acc)[2][2]) {
     static_assert(MB == 2 || MB == 4, "MB");
@@ -148,17 +143,6 @@ __device__ __forceinline__ void gemm_tile_f16x2_v2(const void* __restrict__ Aspl
         v2_dma_group<NBLK>(src, voff, my_plane + stage * V2_STAGE);
 #pragma unroll
         for (int b = 0; b < V2_MB_MAX + V2_NB; ++b) src[b] += V2_STEP;
-    };
-    // touch (waves 0, 1; wave w covers column block w): every line of B block w's planes of step `ts`, clamped to the last step
-    const unsigned long long touch_base = v2_uniform((unsigned long long)(uintptr_t)Bsplit + (size_t)(b_block0 + (wave & 1)) * blk);
-    const unsigned touch_voff = lane * 128;
-    const unsigned touch_lds = __builtin_amdgcn_readfirstlane(lds_base + V2_RING_BYTES + (wave & 1) * 256);
-    auto touch = [&](int ts) {
-        const unsigned long long srcp = touch_base + (size_t)(ts < nk ? ts : nk - 1) * V2_STEP;
-        unsigned keep;
-        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %1, %3\n\ts_mov_b32 m0, %0"
-                     : "=&s"(keep)
-                     : "v"(touch_voff), "s"(touch_lds), "s"(srcp));
     };
     // per-lane read offsets inside a stage: lanes 0-31 take octet 2ks, lanes 32-63 octet 2ks + 1 of their row
     const int r = lane & 31, h = lane >> 5;
@@ -206,34 +190,23 @@ __device__ __forceinline__ void gemm_tile_f16x2_v2(const void* __restrict__ Aspl
         __builtin_amdgcn_sched_group_barrier(0x008, 16, 0);       // the rest
     };
     // step t reads stage t % 3; the DMA of step t + 2 goes into stage (t + 2) % 3 = the one step t - 1 read.
-    // vmcnt at the top of step t: everything OLDER than this wave's own pieces of step t + 1 must have landed.  A touching
-    // wave issues [pieces, touch] per step, so two touches are younger than the pieces of step t (8 / 2 instead of 6 / 0).
-    auto step = [&](int t, auto st, auto st_next2, auto touching) {
-        constexpr int X = decltype(touching)::value ? 2 : 0;
-        if (t + 1 < nk) v2_wait_vmcnt<NBLK + X>(); else v2_wait_vmcnt<X>();
+    // vmcnt at the top of step t: everything OLDER than this wave's own pieces of step t + 1 must have landed.
+    auto step = [&](int t, auto st, auto st_next2) {
+        if (t + 1 < nk) v2_wait_vmcnt<NBLK>(); else v2_wait_vmcnt<0>();
         v2_barrier();
         if (t + 2 < nk) issue(decltype(st_next2)::value);
-        if (X) touch(t + PF);
         compute(st);
     };
-    auto run = [&](auto touching) {
-        int t = 0;
-        for (; t + 2 < nk; t += 3) {
-            step(t, IC<0>{}, IC<2>{}, touching);
-            step(t + 1, IC<1>{}, IC<0>{}, touching);
-            step(t + 2, IC<2>{}, IC<1>{}, touching);
-        }
-        if (t < nk) { step(t, IC<0>{}, IC<2>{}, touching); ++t; }
-        if (t < nk) { step(t, IC<1>{}, IC<0>{}, touching); ++t; }
-    };
-    const bool toucher = PF > 0 && wave < 2;
     issue(0);
-    if (toucher) touch(2);             // keeps the count uniform from step 0 on: [pieces(0), touch, pieces(1), touch]
-    if (nk > 1) {
-        issue(1);
-        if (toucher) touch(3);
+    if (nk > 1) issue(1);
+    int t = 0;
+    for (; t + 2 < nk; t += 3) {
+        step(t, IC<0>{}, IC<2>{});
+        step(t + 1, IC<1>{}, IC<0>{});
+        step(t + 2, IC<2>{}, IC<1>{});
     }
-    if (toucher) run(IC<1>{}); else run(IC<0>{});
+    if (t < nk) { step(t, IC<0>{}, IC<2>{}); ++t; }
+    if (t < nk) { step(t, IC<1>{}, IC<0>{}); ++t; }
     v2_barrier();                      // everybody is done reading: the ring is the caller's
 }
 

@@ -1,5 +1,7 @@
 // Micro-benchmark + accuracy check of the second-generation fp16-split projection tile (csrc/gemm_f16x2_v2.hpp) against
 // the first-generation one (csrc/gemm_f16x2.hpp), on uniform GEMMs with a wide per-row / per-column dynamic range.
+// (The schedule / stagger / 16x16x32 / L2-prefetch studies logged under profiles/r02/proj_v2_*_study.log were run with the
+// variants this file carried at the corresponding round-2 commits; the tile kept the plain form they all lost to.)
 // build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -I nsgp-repre_amd/csrc -o gpurun_out/proj_v2_bench tools/proj_v2_bench.hip
 #include <hip/hip_runtime.h>
 #include <algorithm>
@@ -12,14 +14,14 @@ using namespace nsgp;
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at line %d\n", hipGetErrorString(e_), __LINE__); return 1; } } while (0)
 
 // out[m][n] = rinv[m] * cinv[n] * (A_split x B_split)[m][n]
-template <int MB, int PF = 0>
+template <int MB>
 __global__ __launch_bounds__(V2_THREADS, 2) void v2_kernel(const void* As, const void* Bs, const float* rinv, const float* cinv,
                                                            float* C, int M, int N, int K) {
     extern __shared__ __attribute__((aligned(16))) char smem_c[];
     f32x16 acc[2][2];
     zero_acc(acc);
     const int m0 = blockIdx.y * (MB * 64), n0 = blockIdx.x * 128;
-    gemm_tile_f16x2_v2<MB, PF>(As, m0 / 64, Bs, n0 / 64, K, smem_c, acc);
+    gemm_tile_f16x2_v2<MB>(As, m0 / 64, Bs, n0 / 64, K, smem_c, acc);
     if ((int)(threadIdx.x >> 6) >= 2 * MB) return;
     float* smem = reinterpret_cast<float*>(smem_c);
     acc_to_lds(smem, acc);
@@ -144,60 +146,8 @@ static int run_shape(int M, int N, int K, bool wide_rows) {
     return 0;
 }
 
-// The projector stream as the optimizer step sees it: every launch reads a projector that is NOT resident in the 256 MiB
-// Infinity Cache (R-50-FPN streams 0.58 GB of projectors per step, read once).  NP copies of the split projector are used in
-// rotation, so each launch pulls its B operand from HBM; a resident run (one copy) is timed beside it, and the L2 prefetch
-// distance PF is swept.
-static int run_cold(int M, int N, int K) {
-    float *A, *B, *C, *rinv, *cscale, *cinv; void* As;
-    const size_t bs_bytes = v2_operand_bytes(N, K);
-    const int NP = (int)((size_t)700 * 1024 * 1024 / bs_bytes) + 2;
-    std::vector<void*> Bs(NP);
-    CK(hipMalloc(&A, (size_t)M * K * 4)); CK(hipMalloc(&B, (size_t)K * N * 4)); CK(hipMalloc(&C, (size_t)M * N * 4));
-    CK(hipMalloc(&As, v2_operand_bytes(M, K))); CK(hipMalloc(&rinv, M * 4)); CK(hipMalloc(&cscale, N * 4)); CK(hipMalloc(&cinv, N * 4));
-    for (auto& b : Bs) CK(hipMalloc(&b, bs_bytes));
-    std::vector<float> ha((size_t)M * K), hb((size_t)K * N);
-    unsigned s = 777u;
-    auto rnd = [&]() { s = s * 1664525u + 1013904223u; return ((s >> 8) & 0xffff) / 32768.0f - 1.0f; };
-    for (auto& v : ha) v = rnd() * 1e-3f;
-    for (auto& v : hb) v = rnd() * 0.05f;
-    CK(hipMemcpy(A, ha.data(), ha.size() * 4, hipMemcpyHostToDevice)); CK(hipMemcpy(B, hb.data(), hb.size() * 4, hipMemcpyHostToDevice));
-    hipLaunchKernelGGL(nsgp_split_rows_f16x2_kernel, dim3(M / 8), dim3(256), 0, 0, A, M, K, As, rinv);
-    hipLaunchKernelGGL(nsgp_col_scales_f16x2_kernel, dim3((N + 31) / 32), dim3(256), 0, 0, B, K, N, cscale, cinv);
-    hipLaunchKernelGGL(nsgp_split_transpose_f16x2_v2_kernel, dim3((N + 31) / 32, (K + 31) / 32), dim3(256), 0, 0, B, K, N, cscale, Bs[0]);
-    for (int i = 1; i < NP; ++i) CK(hipMemcpy(Bs[i], Bs[0], bs_bytes, hipMemcpyDeviceToDevice));
-    CK(hipDeviceSynchronize());
-    const double fl = 2.0 * M * N * (double)K;
-    auto tv = [&](auto kern, bool cold) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, V2_SMEM_BYTES);
-        int it = 0;
-        const float t = time_it([&] { hipLaunchKernelGGL(kern, dim3(N / 128, M / 256), dim3(V2_THREADS), V2_SMEM_BYTES, 0, As, Bs[cold ? (it++ % NP) : 0], rinv, cinv, C, M, N, K); });
-        return fl / t / 1e9;
-    };
-    printf("M %d N %d K %d, %d tiles, projector %.0f MB x %d copies in rotation (cold = every launch streams its projector from HBM)\n", M, N, K, (M / 256) * (N / 128), bs_bytes / 1e6, NP);
-    printf("   TF-eq resident : PF0 %.1f  PF4 %.1f  PF8 %.1f\n", tv(v2_kernel<4, 0>, false), tv(v2_kernel<4, 4>, false), tv(v2_kernel<4, 8>, false));
-    printf("   TF-eq cold     : PF0 %.1f  PF3 %.1f  PF4 %.1f  PF6 %.1f  PF8 %.1f  PF12 %.1f\n", tv(v2_kernel<4, 0>, true), tv(v2_kernel<4, 3>, true), tv(v2_kernel<4, 4>, true),
-           tv(v2_kernel<4, 6>, true), tv(v2_kernel<4, 8>, true), tv(v2_kernel<4, 12>, true));
-    printf("   TF-eq cold again: PF0 %.1f  PF4 %.1f  PF8 %.1f\n", tv(v2_kernel<4, 0>, true), tv(v2_kernel<4, 4>, true), tv(v2_kernel<4, 8>, true));
-    // the touches must not change a single bit
-    std::vector<float> c0((size_t)M * N), c1((size_t)M * N);
-    hipLaunchKernelGGL((v2_kernel<4, 0>), dim3(N / 128, M / 256), dim3(V2_THREADS), V2_SMEM_BYTES, 0, As, Bs[0], rinv, cinv, C, M, N, K);
-    CK(hipMemcpy(c0.data(), C, c0.size() * 4, hipMemcpyDeviceToHost));
-    hipLaunchKernelGGL((v2_kernel<4, 6>), dim3(N / 128, M / 256), dim3(V2_THREADS), V2_SMEM_BYTES, 0, As, Bs[1], rinv, cinv, C, M, N, K);
-    CK(hipMemcpy(c1.data(), C, c1.size() * 4, hipMemcpyDeviceToHost));
-    size_t bad = 0; for (size_t i = 0; i < c0.size(); ++i) bad += c0[i] != c1[i];
-    printf("   PF6 vs PF0 output: %zu differing elements\n", bad);
-    return 0;
-}
-
 int main(int argc, char** argv) {
     int rc = 0;
-    if (argc > 1) {      // prefetch study: the projector streamed from HBM, as in the optimizer step
-        rc |= run_cold(1792, 4608, 4608);     // 252 tiles of 144 steps: one round on 256 CUs
-        rc |= run_cold(1792, 2304, 2304);     // 126 tiles of 72 steps
-        rc |= run_cold(3584, 2304, 2304);     // 252 tiles of 72 steps
-        return rc;
-    }
     rc |= run_shape(512, 512, 512, true);        // small: 4 x 2 tiles, mostly a correctness case
     rc |= run_shape(4096, 4096, 4096, true);
     rc |= run_shape(4096, 4096, 4096, false);
