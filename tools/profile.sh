@@ -2,11 +2,11 @@
 # Profile bench.py on the GPU box: kernel trace + stats, then separate PMC passes.
 # Usage (on the GPU box, from the repo root): bash tools/profile.sh <tag>
 set -o pipefail
-TAG=${1:-r01}
+TAG=${1:-r02}
 OUT=gpurun_out/prof_$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
-B="python3 bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-end-to-end"
+B="python3 bench.py --steps 10 --warmup 2 --hot-path-only"
 echo "trace pass" >> gpurun_out/profile_progress.log
 timeout -k 10 170 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o trace -- $B > $OUT/trace.log 2>&1 || echo "trace failed" >> $OUT/trace.log
 echo "pmc pass" >> gpurun_out/profile_progress.log

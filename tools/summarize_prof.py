@@ -71,9 +71,14 @@ for k in agg:
     if "FETCH_SIZE" in agg[k] and "WRITE_SIZE" in agg[k]:
         f = sum(agg[k]["FETCH_SIZE"]) / len(agg[k]["FETCH_SIZE"])
         w = sum(agg[k]["WRITE_SIZE"]) / len(agg[k]["WRITE_SIZE"])
-        json.dump({"kernel": k, "nsgp_project_kernel_hbm_bytes_per_launch": f * 1024 * 2 + w * 1024,
+        extra = {}
+        if "SQ_VALU_MFMA_BUSY_CYCLES" in agg[k] and "GRBM_GUI_ACTIVE" in agg[k]:
+            busy = sum(agg[k]["SQ_VALU_MFMA_BUSY_CYCLES"]) / len(agg[k]["SQ_VALU_MFMA_BUSY_CYCLES"])
+            gui = sum(agg[k]["GRBM_GUI_ACTIVE"]) / len(agg[k]["GRBM_GUI_ACTIVE"])
+            extra["mfma_busy_fraction"] = busy / (1024 * gui / 8)      # 1024 SIMDs x cycles per XCD (GRBM_GUI_ACTIVE sums 8 XCDs)
+            extra["mfma_busy_note"] = "SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x GRBM_GUI_ACTIVE / 8)"
+        json.dump({"kernel": k, **extra, "nsgp_project_kernel_hbm_bytes_per_launch": f * 1024 * 2 + w * 1024,
                    "fetch_size_kib_raw": f, "write_size_kib_raw": w,
-                   "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE passes of `python3 bench.py --steps 10 --warmup 2 "
-                             "--no-cpu-baseline` (tools/profile.sh); FETCH_SIZE x2 per the gfx950 correction"},
+                   "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE passes of `python3 bench.py --steps 10 --warmup 2 --hot-path-only` (tools/profile.sh); FETCH_SIZE x2 per the gfx950 correction"},
                   open(os.path.join(dst, "traffic.json"), "w"), indent=1)
         break
