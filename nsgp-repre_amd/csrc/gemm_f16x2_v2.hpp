@@ -114,7 +114,11 @@ __device__ __forceinline__ void v2_dma_group(const unsigned long long (&src)[V2_
 // Measured and not kept (tools/proj_v2_bench.hip at its round-2 commits; profiles/r02/proj_v2_schedule_study.log): staggering the
 // DMA issue of the two waves that share a SIMD (-5 % at sustained clocks); other LDS-read / MFMA interleaves (all reads first, the
 // compiler's own order, 4 reads then one per MFMA: within 2 %); the v_mfma_f32_16x16x32_f16 form of the step (the same 415 TF-eq).
-// Also measured and not kept (profiles/r02/proj_v2_prefetch_study.log): an L2 prefetch of the projector stream (the one operand
+// Also measured and not kept: the same pipeline as 128 x 128 tiles of 256 threads with TWO independent workgroups per CU (k16
+// steps, 3-5 stage ring; tools/proj_v2_bench.hip carries it, profiles/r02/proj_v2_two_wg_study.log): bit-identical results,
+// 390-403 against 412-425 TF-eq on full rounds of a uniform GEMM, up to +40 % on launches that under-fill the chip, and the
+// same 0.34 ms (+-1 %) on the R-50 / R-101 tables -- finer list scheduling and separate barriers buy what the halved projector
+// reuse costs.  And (profiles/r02/proj_v2_prefetch_study.log): an L2 prefetch of the projector stream (the one operand
 // that comes from HBM) by 4-byte "touch" loads 3-12 steps ahead -- with the projector rotated through 700 MB of copies so that
 // every launch streams it from HBM, the kernel runs at the SAME rate as with a cache-resident projector (410 vs 380-400 TF-eq)
 // and the touches cost 2.5 %: two steps of DMA prefetch already cover the HBM round trip.
