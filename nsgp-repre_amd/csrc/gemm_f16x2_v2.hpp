@@ -1,5 +1,6 @@
 // fp32-accurate projection GEMM on the fp16 matrix cores, second generation: BOTH operands arrive pre-split and
-// pre-tiled, and travel global -> LDS by LDS-DMA (global_load_lds_dwordx4); the main loop holds MFMAs and LDS reads only.
+// pre-tiled, and travel global -> LDS by LDS-DMA (global_load_lds_dwordx4) issued by dedicated LOADER waves; the consumer
+// waves' main loop holds MFMAs and LDS reads only.
 //
 // Arithmetic (as gemm_f16x2.hpp): x = x0 + x1, x0 = fp16(s x), x1 = fp16(s x - x0), a*b ~= a1 b0 + a0 b1 + a0 b0 -- three
 // v_mfma_f32_32x32x16_f16 per fp32-equivalent product, fp32 accumulation, smallest terms first.  What changed is the scale s:
@@ -17,14 +18,24 @@
 // (the hardware's 16-lane groups cover rows that are distinct mod 16).  Per 64-row block a k32 step is 8 planes = 8 KiB
 // contiguous.
 //
-// Tile: 256 x 128 (MB = 4 row blocks x 2 column blocks), 512 threads = 8 waves as 4 (M) x 2 (N), 64 x 64 per wave as 2 x 2
-// MFMA blocks; ONE workgroup per CU.  The projector -- the operand that comes from HBM, 4 B per element -- is shared by twice
-// the rows of the first-generation 128 x 128 tile: 32 B/clk/CU from L2 at full MFMA rate instead of 43.
-// LDS: three 48 KiB stages (144 of the CU's 160 KiB).  K-step t: wave w waits for ITS OWN pieces of stage t (counted vmcnt
-// that leaves step t+1's in flight), one raw s_barrier (everybody's pieces of t have landed AND everybody is done reading
-// stage t-1); the DMA of step t+2 goes into the stage t-1 used; 16 ds_read_b128 + 24 MFMAs.  The prefetch distance is two
-// full steps (~3000 cycles); the barrier is the only synchronisation per step.
-// MB = 2 serves the 128-row layers (and a trailing 128-row remainder): the same code with waves 4-7 idle in the MFMA part.
+// Tile: 256 x 128 (MB = 4 row blocks x 2 column blocks), ONE workgroup of 768 threads per CU: waves 0-7 are consumers (4 (M) x
+// 2 (N), 64 x 64 per wave as 2 x 2 MFMA blocks), waves 8-11 loaders.  The projector -- the operand that comes from HBM, 4 B per
+// element -- is shared by twice the rows of the first-generation 128 x 128 tile: 32 B/clk/CU from L2 at full MFMA rate
+// instead of 43.  LDS: three 48 KiB stages (144 of the CU's 160 KiB).  K-step t: each loader waits for ITS OWN pieces of
+// stage t (counted vmcnt that leaves step t+1's in flight), all twelve waves meet at ONE raw s_barrier (everybody's pieces of t
+// have landed AND every consumer is done reading stage t-1); the loaders issue the pieces of step t+2 into the stage t-1
+// used, the consumers do 16 ds_read_b128 + 24 MFMAs.  Prefetch distance two full steps (~2.4 us).
+// MB = 2 serves the 128-row layers (and a trailing 128-row remainder): the same code with consumer waves 4-7 idle.
+//
+// Measured and not kept -- the variants live in tools/proj_v2_bench.hip, their logs in profiles/r02/proj_v2_*_study.log:
+//   * every wave issuing its own six pieces right after the barrier (512 threads, no loaders): the first form of this tile,
+//     418 against 426-434 TF-eq on full rounds of a uniform GEMM, 0.340 against 0.320 ms on the R-50 table;
+//   * staggering that DMA issue between the two waves of a SIMD (-5 %); other LDS-read / MFMA interleaves (+-2 %);
+//     the v_mfma_f32_16x16x32_f16 form of the step (same rate);
+//   * 128 x 128 tiles of 256 threads, two independent workgroups per CU (bit-identical; up to +40 % on launches that
+//     under-fill the chip, -5 % on full rounds, +-1 % on the tables);
+//   * an L2 prefetch of the projector stream by 4-byte "touch" loads 3-12 steps ahead: with every launch streaming its
+//     projector from HBM (700 MB of copies in rotation) the kernel already runs at the cache-resident rate; touches cost 2.5 %.
 #pragma once
 #include "gemm_core.hpp"
 #include "gemm_f16x2.hpp"
@@ -41,7 +52,6 @@ constexpr int V2_STAGE = (V2_MB_MAX + V2_NB) * V2_STEP; // 48 KiB
 constexpr int V2_STAGES = 3;
 constexpr int V2_RING_BYTES = V2_STAGES * V2_STAGE;     // 147,456 B
 constexpr int V2_SMEM_BYTES = V2_RING_BYTES;
-constexpr int V2_THREADS = 512;
 static_assert(8 * 64 * EPI_LD * 4 <= V2_RING_BYTES, "the epilogue re-layout (16 KiB per wave) must fit the ring");
 
 typedef __attribute__((address_space(3))) char lds_char;
@@ -52,12 +62,12 @@ __host__ __device__ __forceinline__ size_t v2_plane_offset(int block, int octet,
 }
 __host__ __device__ __forceinline__ size_t v2_operand_bytes(int rows, int K) { return (size_t)rows * K * 4; }
 
-template <int N>
-__device__ __forceinline__ void v2_wait_vmcnt() {
-    static_assert(N == 0 || N == 4 || N == 6, "counts: 0, 4 (MB = 2), 6 (MB = 4)");
-    if constexpr (N == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    else if constexpr (N == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+// one LDS-DMA piece: the 1 KiB at `src` + lane * 16 -> LDS byte address `lds` + lane * 16
+__device__ __forceinline__ void v2_dma_one(unsigned long long src, unsigned voff, unsigned lds) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %3\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(voff), "s"(lds), "s"(src));
 }
 
 // raw barrier (a __syncthreads() would drain the LDS-DMA prefetch with vmcnt(0)); the empty asms keep the compiler from
@@ -73,90 +83,68 @@ __device__ __forceinline__ unsigned long long v2_uniform(unsigned long long x) {
     return ((unsigned long long)hi << 32) | lo;
 }
 
-// NBLK LDS-DMA pieces of one wave in ONE asm statement (nothing can be scheduled in between): piece b moves the 1 KiB at
-// src[slot b] + lane * 16 to LDS byte address lds0 + slot * V2_STEP + lane * 16.  M0 carries the LDS destination; it is
-// compiler-reserved, so it is saved and restored around the group.
-template <int NBLK>
-__device__ __forceinline__ void v2_dma_group(const unsigned long long (&src)[V2_MB_MAX + V2_NB], unsigned voff, unsigned lds0) {
-    unsigned keep;
-    if constexpr (NBLK == 6) {
-        asm volatile(
-            "s_mov_b32 %0, m0\n\t"
-            "s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %3\n\t"
-            "s_add_u32 m0, m0, 0x2000\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %4\n\t"
-            "s_add_u32 m0, m0, 0x2000\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %5\n\t"
-            "s_add_u32 m0, m0, 0x2000\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %6\n\t"
-            "s_add_u32 m0, m0, 0x2000\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %7\n\t"
-            "s_add_u32 m0, m0, 0x2000\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %8\n\t"
-            "s_mov_b32 m0, %0"
-            : "=&s"(keep)
-            : "v"(voff), "s"(lds0), "s"(src[0]), "s"(src[1]), "s"(src[2]), "s"(src[3]), "s"(src[4]), "s"(src[5])
-            : "scc");
-    } else {
-        static_assert(NBLK == 4, "tiles have 4 + 2 or 2 + 2 blocks");
-        // MB = 2: blocks 0,1 are A (LDS slots 0,1), blocks 4,5 are B (LDS slots 4,5)
-        asm volatile(
-            "s_mov_b32 %0, m0\n\t"
-            "s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %3\n\t"
-            "s_add_u32 m0, m0, 0x2000\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %4\n\t"
-            "s_add_u32 m0, m0, 0x6000\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %5\n\t"
-            "s_add_u32 m0, m0, 0x2000\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %6\n\t"
-            "s_mov_b32 m0, %0"
-            : "=&s"(keep)
-            : "v"(voff), "s"(lds0), "s"(src[0]), "s"(src[1]), "s"(src[4]), "s"(src[5])
-            : "scc");
-    }
-}
+// ---- the tile: acc += A[rows of blocks a_block0 .. +MB) x B[cols of blocks b_block0, +1], both pre-tiled / pre-split, K % 32 == 0
+// 768 threads: waves 0-7 are CONSUMERS (4 x 2, 64 x 64 each: LDS reads + MFMAs, nothing else), waves 8-11 are LOADERS that
+// issue all 48 (MB = 2: 32) DMA pieces of a step and never touch the matrix pipe.  (When every wave loads, each spends the
+// head of each step issuing its six LDS-DMA pieces -- ~100-180 cycles apiece while the CU's memory pipeline is taking 48 KiB --
+// with BOTH waves of a SIMD stuck there together and the matrix pipe idle; here the matrix work starts right behind the
+// barrier.)  One barrier per step for all twelve waves.  On return every wave has passed a barrier after the last LDS read and
+// no DMA is in flight: the ring is the caller's (only waves 0 .. 2 MB - 1 hold accumulators).
+//   loader l (0..3): planes 2l, 2l+1 (octet l, both terms) of every block slot -> 12 (8) pieces per step, counted vmcnt(12 / 8).
+constexpr int V2L_THREADS = 768;
 
-// acc += A[rows of blocks a_block0 .. +MB) x B[cols of blocks b_block0, b_block0 + 1), both pre-tiled / pre-split with K
-// columns (K % 32 == 0).  512 threads.  On return every wave has passed a barrier after its last LDS read and no DMA is
-// in flight: the ring is free for the caller's epilogue.
-// Measured and not kept (tools/proj_v2_bench.hip at its round-2 commits; profiles/r02/proj_v2_schedule_study.log): staggering the
-// DMA issue of the two waves that share a SIMD (-5 % at sustained clocks); other LDS-read / MFMA interleaves (all reads first, the
-// compiler's own order, 4 reads then one per MFMA: within 2 %); the v_mfma_f32_16x16x32_f16 form of the step (the same 415 TF-eq).
-// Also measured and not kept: the same pipeline as 128 x 128 tiles of 256 threads with TWO independent workgroups per CU (k16
-// steps, 3-5 stage ring; tools/proj_v2_bench.hip carries it, profiles/r02/proj_v2_two_wg_study.log): bit-identical results,
-// 390-403 against 412-425 TF-eq on full rounds of a uniform GEMM, up to +40 % on launches that under-fill the chip, and the
-// same 0.34 ms (+-1 %) on the R-50 / R-101 tables -- finer list scheduling and separate barriers buy what the halved projector
-// reuse costs.  And (profiles/r02/proj_v2_prefetch_study.log): an L2 prefetch of the projector stream (the one operand
-// that comes from HBM) by 4-byte "touch" loads 3-12 steps ahead -- with the projector rotated through 700 MB of copies so that
-// every launch streams it from HBM, the kernel runs at the SAME rate as with a cache-resident projector (410 vs 380-400 TF-eq)
-// and the touches cost 2.5 %: two steps of DMA prefetch already cover the HBM round trip.
 template <int MB>
-__device__ __forceinline__ void gemm_tile_f16x2_v2(const void* __restrict__ Asplit, int a_block0, const void* __restrict__ Bsplit,
-                                                   int b_block0, int K, char* smem, f32x16 (&acc)[2][2]) {
+__device__ __forceinline__ void gemm_tile_f16x2_v2l(const void* __restrict__ Asplit, int a_block0, const void* __restrict__ Bsplit,
+                                                    int b_block0, int K, char* smem, f32x16 (&acc)[2][2]) {
     static_assert(MB == 2 || MB == 4, "MB");
-    constexpr int NBLK = MB + V2_NB;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int wm = wave >> 1, wn = wave & 1;
-    const size_t blk = (size_t)K * 256;                                 // bytes of one 64-row block
-    // block slots of a stage: 0..3 = A row blocks, 4..5 = B column blocks; MB = 2 leaves slots 2, 3 unused
-    unsigned long long src[V2_MB_MAX + V2_NB];
-#pragma unroll
-    for (int b = 0; b < V2_MB_MAX; ++b)
-        src[b] = v2_uniform((unsigned long long)(uintptr_t)Asplit + (size_t)(a_block0 + (b < MB ? b : 0)) * blk + (size_t)wave * V2_PLANE);
-#pragma unroll
-    for (int b = 0; b < V2_NB; ++b)
-        src[V2_MB_MAX + b] = v2_uniform((unsigned long long)(uintptr_t)Bsplit + (size_t)(b_block0 + b) * blk + (size_t)wave * V2_PLANE);
-    const unsigned voff = lane * 16;
-    const unsigned lds_base = (unsigned)(size_t)(lds_char*)smem;
-    const unsigned my_plane = __builtin_amdgcn_readfirstlane(lds_base + wave * V2_PLANE);
+    const size_t blk = (size_t)K * 256;
     const int nk = K / V2_BK;
-    auto issue = [&](int stage) {      // the pieces of the NEXT un-issued step into `stage`; advances the source pointers
-        v2_dma_group<NBLK>(src, voff, my_plane + stage * V2_STAGE);
+    if (wave >= 8) {
+        // ------------------------------------------------------------------ loader
+        constexpr int NPIECE = 2 * (MB + V2_NB);
+        const int l = wave - 8;
+        unsigned long long src[V2_MB_MAX + V2_NB];
 #pragma unroll
-        for (int b = 0; b < V2_MB_MAX + V2_NB; ++b) src[b] += V2_STEP;
-    };
-    // per-lane read offsets inside a stage: lanes 0-31 take octet 2ks, lanes 32-63 octet 2ks + 1 of their row
+        for (int b = 0; b < V2_MB_MAX; ++b)
+            src[b] = v2_uniform((unsigned long long)(uintptr_t)Asplit + (size_t)(a_block0 + (b < MB ? b : 0)) * blk + (size_t)l * (2 * V2_PLANE));
+#pragma unroll
+        for (int b = 0; b < V2_NB; ++b)
+            src[V2_MB_MAX + b] = v2_uniform((unsigned long long)(uintptr_t)Bsplit + (size_t)(b_block0 + b) * blk + (size_t)l * (2 * V2_PLANE));
+        const unsigned voff = lane * 16;
+        const unsigned my_planes = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(lds_char*)smem + l * (2 * V2_PLANE));
+        auto issue = [&](int stage) {
+#pragma unroll
+            for (int b = 0; b < V2_MB_MAX + V2_NB; ++b) {
+                if (MB == 2 && (b == 2 || b == 3)) continue;
+                v2_dma_one(src[b], voff, my_planes + stage * V2_STAGE + b * V2_STEP);
+                v2_dma_one(src[b] + V2_PLANE, voff, my_planes + stage * V2_STAGE + b * V2_STEP + V2_PLANE);
+                src[b] += V2_STEP;
+            }
+        };
+        auto lstep = [&](int t, auto st_next2) {
+            if (t + 1 < nk) { if constexpr (NPIECE == 12) asm volatile("s_waitcnt vmcnt(12)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); }
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            v2_barrier();
+            if (t + 2 < nk) issue(decltype(st_next2)::value);
+        };
+        issue(0);
+        if (nk > 1) issue(1);
+        int t = 0;
+        for (; t + 2 < nk; t += 3) { lstep(t, IC<2>{}); lstep(t + 1, IC<0>{}); lstep(t + 2, IC<1>{}); }
+        if (t < nk) { lstep(t, IC<2>{}); ++t; }
+        if (t < nk) { lstep(t, IC<0>{}); ++t; }
+        v2_barrier();
+        return;
+    }
+    // ---------------------------------------------------------------------- consumer
+    const int wm = wave >> 1, wn = wave & 1;
     const int r = lane & 31, h = lane >> 5;
     const lds_char* abase = (const lds_char*)smem + wm * V2_STEP + h * (2 * V2_PLANE) + r * 16;
     const lds_char* bbase = (const lds_char*)smem + (V2_MB_MAX + wn) * V2_STEP + h * (2 * V2_PLANE) + r * 16;
-    const bool active = wm < MB;       // MB = 2: waves 4-7 only move data
+    const bool active = wm < MB;
     typedef const __attribute__((address_space(3))) h16x8* lds_frag;
-    // One step = 16 ds_read_b128 (two k16 halves x {a0, a1, b0, b1} x two 32-row blocks) + 24 MFMAs.  The schedule is pinned
-    // with sched_group_barriers: four reads, then one read behind each of the next twelve MFMAs, then the remaining MFMAs --
-    // left alone, hipcc issues 4 reads, waits, 4 MFMAs, ... with the matrix pipe idle during every wait.
     auto compute = [&](auto st) {
         constexpr int ST = decltype(st)::value;
         if (!active) return;
@@ -171,7 +159,7 @@ __device__ __forceinline__ void gemm_tile_f16x2_v2(const void* __restrict__ Aspl
                     fb[ks][i][p] = *reinterpret_cast<lds_frag>(bbase + ST * V2_STAGE + ks * (4 * V2_PLANE) + p * V2_PLANE + i * 512);
                 }
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {    // smallest terms first; consecutive MFMAs belong to four independent accumulator chains
+        for (int ks = 0; ks < 2; ++ks) {
 #pragma unroll
             for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
@@ -185,33 +173,23 @@ __device__ __forceinline__ void gemm_tile_f16x2_v2(const void* __restrict__ Aspl
 #pragma unroll
                 for (int ni = 0; ni < 2; ++ni) acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[ks][mi][0], fb[ks][ni][0], acc[mi][ni], 0, 0, 0);
         }
-        __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);        // 8 DS reads (first k16 half)
+        __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
-            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);    // 1 MFMA
-            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);    // 1 DS read (second half)
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
         }
-        __builtin_amdgcn_sched_group_barrier(0x008, 16, 0);       // the rest
+        __builtin_amdgcn_sched_group_barrier(0x008, 16, 0);
     };
-    // step t reads stage t % 3; the DMA of step t + 2 goes into stage (t + 2) % 3 = the one step t - 1 read.
-    // vmcnt at the top of step t: everything OLDER than this wave's own pieces of step t + 1 must have landed.
-    auto step = [&](int t, auto st, auto st_next2) {
-        if (t + 1 < nk) v2_wait_vmcnt<NBLK>(); else v2_wait_vmcnt<0>();
-        v2_barrier();
-        if (t + 2 < nk) issue(decltype(st_next2)::value);
-        compute(st);
-    };
-    issue(0);
-    if (nk > 1) issue(1);
     int t = 0;
     for (; t + 2 < nk; t += 3) {
-        step(t, IC<0>{}, IC<2>{});
-        step(t + 1, IC<1>{}, IC<0>{});
-        step(t + 2, IC<2>{}, IC<1>{});
+        v2_barrier(); compute(IC<0>{});
+        v2_barrier(); compute(IC<1>{});
+        v2_barrier(); compute(IC<2>{});
     }
-    if (t < nk) { step(t, IC<0>{}, IC<2>{}); ++t; }
-    if (t < nk) { step(t, IC<1>{}, IC<0>{}); ++t; }
-    v2_barrier();                      // everybody is done reading: the ring is the caller's
+    if (t < nk) { v2_barrier(); compute(IC<0>{}); ++t; }
+    if (t < nk) { v2_barrier(); compute(IC<1>{}); ++t; }
+    v2_barrier();
 }
 
 // ---- operand preparation ------------------------------------------------------------------------------------------------

@@ -346,9 +346,9 @@ __global__ __launch_bounds__(256, 2) void nsgp_project_kernel(const TileDev* __r
 }
 
 // fp16-split path (gemm_f16x2_v2.hpp): p += scale * rinv[m] * cinv[n] * (A_split x B_split), 256 x 128 tiles (t.pad = 4 row
-// blocks) or 128 x 128 (t.pad = 2), 512 threads, one workgroup per CU.
+// blocks) or 128 x 128 (t.pad = 2); 768 threads = 8 consumer + 4 loader waves, one workgroup per CU.
 template <int OPT>
-__global__ __launch_bounds__(V2_THREADS, 2) void nsgp_project_v2_kernel(const TileDev* __restrict__ tiles,
+__global__ __launch_bounds__(V2L_THREADS, 3) void nsgp_project_v2_kernel(const TileDev* __restrict__ tiles,
                                                                         const LayerDev* __restrict__ layers,
                                                                         const DynBlock* __restrict__ dyn) {
     extern __shared__ __attribute__((aligned(16))) char smem_c[];
@@ -357,9 +357,9 @@ __global__ __launch_bounds__(V2_THREADS, 2) void nsgp_project_v2_kernel(const Ti
     const float scale = (OPT == NSGP_OPT_SGD) ? -dyn->hyper[L.hyper].lr : 1.0f;   // update = -(lr * grad), SGD_NSCL.py:413
     f32x16 acc[2][2];
     zero_acc(acc);
-    if (t.pad == 4) gemm_tile_f16x2_v2<4>(L.a_split, t.m0 >> 6, L.split, t.n0 >> 6, L.cols, smem_c, acc);
-    else gemm_tile_f16x2_v2<2>(L.a_split, t.m0 >> 6, L.split, t.n0 >> 6, L.cols, smem_c, acc);
-    if ((int)(threadIdx.x >> 6) >= 2 * t.pad) return;      // 128-row tile: waves 4-7 only moved data
+    if (t.pad == 4) gemm_tile_f16x2_v2l<4>(L.a_split, t.m0 >> 6, L.split, t.n0 >> 6, L.cols, smem_c, acc);
+    else gemm_tile_f16x2_v2l<2>(L.a_split, t.m0 >> 6, L.split, t.n0 >> 6, L.cols, smem_c, acc);
+    if ((int)(threadIdx.x >> 6) >= 2 * t.pad) return;      // the four loader waves; and waves 4-7 of a 128-row tile, which have no rows
     float* smem = reinterpret_cast<float*>(smem_c);
     acc_to_lds(smem, acc);
     __builtin_amdgcn_s_waitcnt(0xc07f);                    // lgkmcnt(0): this wave's own LDS writes have landed
@@ -933,9 +933,9 @@ extern "C" int nsgp_plan_step(nsgp_plan_t* P, float* const* grads, const nsgp_hy
     if (P->n_tiles_v2 > 0) {
         const TileDev* vt = P->d_tiles + P->n_tiles_fast + P->n_tiles_generic + P->n_tiles_lr1 + P->n_tiles_lr2;
         if (P->optimizer == NSGP_OPT_SGD)
-            hipLaunchKernelGGL(nsgp_project_v2_kernel<NSGP_OPT_SGD>, dim3(P->n_tiles_v2), dim3(V2_THREADS), V2_SMEM_BYTES, stream, vt, P->d_layers, d);
+            hipLaunchKernelGGL(nsgp_project_v2_kernel<NSGP_OPT_SGD>, dim3(P->n_tiles_v2), dim3(V2L_THREADS), V2_SMEM_BYTES, stream, vt, P->d_layers, d);
         else
-            hipLaunchKernelGGL(nsgp_project_v2_kernel<NSGP_OPT_ADAM>, dim3(P->n_tiles_v2), dim3(V2_THREADS), V2_SMEM_BYTES, stream, vt, P->d_layers, d);
+            hipLaunchKernelGGL(nsgp_project_v2_kernel<NSGP_OPT_ADAM>, dim3(P->n_tiles_v2), dim3(V2L_THREADS), V2_SMEM_BYTES, stream, vt, P->d_layers, d);
         NSGP_LAUNCH_CHECK();
     }
     if (P->n_tiles_fast > 0) {

@@ -12,7 +12,160 @@
 using namespace nsgp;
 
 namespace nsgp {
-// STUDY VARIANT (not in the library; DESIGN.md section 4 "measured and not kept"):
+// STUDY VARIANTS (not in the library; DESIGN.md section 4 "measured and not kept").
+// (1) the first form of the 256 x 128 tile: 512 threads, every wave issues its own six DMA pieces right after the barrier.
+constexpr int V2_THREADS = 512;
+template <int N>
+__device__ __forceinline__ void v2_wait_vmcnt() {
+    static_assert(N == 0 || N == 4 || N == 6, "counts: 0, 4 (MB = 2), 6 (MB = 4)");
+    if constexpr (N == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    else if constexpr (N == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+}
+
+// NBLK LDS-DMA pieces of one wave in ONE asm statement (nothing can be scheduled in between): piece b moves the 1 KiB at
+// src[slot b] + lane * 16 to LDS byte address lds0 + slot * V2_STEP + lane * 16.  M0 carries the LDS destination; it is
+// compiler-reserved, so it is saved and restored around the group.
+template <int NBLK>
+__device__ __forceinline__ void v2_dma_group(const unsigned long long (&src)[V2_MB_MAX + V2_NB], unsigned voff, unsigned lds0) {
+    unsigned keep;
+    if constexpr (NBLK == 6) {
+        asm volatile(
+            "s_mov_b32 %0, m0\n\t"
+            "s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %3\n\t"
+            "s_add_u32 m0, m0, 0x2000\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %4\n\t"
+            "s_add_u32 m0, m0, 0x2000\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %5\n\t"
+            "s_add_u32 m0, m0, 0x2000\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %6\n\t"
+            "s_add_u32 m0, m0, 0x2000\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %7\n\t"
+            "s_add_u32 m0, m0, 0x2000\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %8\n\t"
+            "s_mov_b32 m0, %0"
+            : "=&s"(keep)
+            : "v"(voff), "s"(lds0), "s"(src[0]), "s"(src[1]), "s"(src[2]), "s"(src[3]), "s"(src[4]), "s"(src[5])
+            : "scc");
+    } else {
+        static_assert(NBLK == 4, "tiles have 4 + 2 or 2 + 2 blocks");
+        // MB = 2: blocks 0,1 are A (LDS slots 0,1), blocks 4,5 are B (LDS slots 4,5)
+        asm volatile(
+            "s_mov_b32 %0, m0\n\t"
+            "s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %3\n\t"
+            "s_add_u32 m0, m0, 0x2000\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %4\n\t"
+            "s_add_u32 m0, m0, 0x6000\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %5\n\t"
+            "s_add_u32 m0, m0, 0x2000\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %6\n\t"
+            "s_mov_b32 m0, %0"
+            : "=&s"(keep)
+            : "v"(voff), "s"(lds0), "s"(src[0]), "s"(src[1]), "s"(src[4]), "s"(src[5])
+            : "scc");
+    }
+}
+
+// acc += A[rows of blocks a_block0 .. +MB) x B[cols of blocks b_block0, b_block0 + 1), both pre-tiled / pre-split with K
+// columns (K % 32 == 0).  512 threads.  On return every wave has passed a barrier after its last LDS read and no DMA is
+// in flight: the ring is free for the caller's epilogue.
+// Measured and not kept (tools/proj_v2_bench.hip at its round-2 commits; profiles/r02/proj_v2_schedule_study.log): staggering the
+// DMA issue of the two waves that share a SIMD (-5 % at sustained clocks); other LDS-read / MFMA interleaves (all reads first, the
+// compiler's own order, 4 reads then one per MFMA: within 2 %); the v_mfma_f32_16x16x32_f16 form of the step (the same 415 TF-eq).
+// Also measured and not kept: the same pipeline as 128 x 128 tiles of 256 threads with TWO independent workgroups per CU (k16
+// steps, 3-5 stage ring; tools/proj_v2_bench.hip carries it, profiles/r02/proj_v2_two_wg_study.log): bit-identical results,
+// 390-403 against 412-425 TF-eq on full rounds of a uniform GEMM, up to +40 % on launches that under-fill the chip, and the
+// same 0.34 ms (+-1 %) on the R-50 / R-101 tables -- finer list scheduling and separate barriers buy what the halved projector
+// reuse costs.  And (profiles/r02/proj_v2_prefetch_study.log): an L2 prefetch of the projector stream (the one operand
+// that comes from HBM) by 4-byte "touch" loads 3-12 steps ahead -- with the projector rotated through 700 MB of copies so that
+// every launch streams it from HBM, the kernel runs at the SAME rate as with a cache-resident projector (410 vs 380-400 TF-eq)
+// and the touches cost 2.5 %: two steps of DMA prefetch already cover the HBM round trip.
+template <int MB>
+__device__ __forceinline__ void gemm_tile_f16x2_v2(const void* __restrict__ Asplit, int a_block0, const void* __restrict__ Bsplit,
+                                                   int b_block0, int K, char* smem, f32x16 (&acc)[2][2]) {
+    static_assert(MB == 2 || MB == 4, "MB");
+    constexpr int NBLK = MB + V2_NB;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const size_t blk = (size_t)K * 256;                                 // bytes of one 64-row block
+    // block slots of a stage: 0..3 = A row blocks, 4..5 = B column blocks; MB = 2 leaves slots 2, 3 unused
+    unsigned long long src[V2_MB_MAX + V2_NB];
+#pragma unroll
+    for (int b = 0; b < V2_MB_MAX; ++b)
+        src[b] = v2_uniform((unsigned long long)(uintptr_t)Asplit + (size_t)(a_block0 + (b < MB ? b : 0)) * blk + (size_t)wave * V2_PLANE);
+#pragma unroll
+    for (int b = 0; b < V2_NB; ++b)
+        src[V2_MB_MAX + b] = v2_uniform((unsigned long long)(uintptr_t)Bsplit + (size_t)(b_block0 + b) * blk + (size_t)wave * V2_PLANE);
+    const unsigned voff = lane * 16;
+    const unsigned lds_base = (unsigned)(size_t)(lds_char*)smem;
+    const unsigned my_plane = __builtin_amdgcn_readfirstlane(lds_base + wave * V2_PLANE);
+    const int nk = K / V2_BK;
+    auto issue = [&](int stage) {      // the pieces of the NEXT un-issued step into `stage`; advances the source pointers
+        v2_dma_group<NBLK>(src, voff, my_plane + stage * V2_STAGE);
+#pragma unroll
+        for (int b = 0; b < V2_MB_MAX + V2_NB; ++b) src[b] += V2_STEP;
+    };
+    // per-lane read offsets inside a stage: lanes 0-31 take octet 2ks, lanes 32-63 octet 2ks + 1 of their row
+    const int r = lane & 31, h = lane >> 5;
+    const lds_char* abase = (const lds_char*)smem + wm * V2_STEP + h * (2 * V2_PLANE) + r * 16;
+    const lds_char* bbase = (const lds_char*)smem + (V2_MB_MAX + wn) * V2_STEP + h * (2 * V2_PLANE) + r * 16;
+    const bool active = wm < MB;       // MB = 2: waves 4-7 only move data
+    typedef const __attribute__((address_space(3))) h16x8* lds_frag;
+    // One step = 16 ds_read_b128 (two k16 halves x {a0, a1, b0, b1} x two 32-row blocks) + 24 MFMAs.  The schedule is pinned
+    // with sched_group_barriers: four reads, then one read behind each of the next twelve MFMAs, then the remaining MFMAs --
+    // left alone, hipcc issues 4 reads, waits, 4 MFMAs, ... with the matrix pipe idle during every wait.
+    auto compute = [&](auto st) {
+        constexpr int ST = decltype(st)::value;
+        if (!active) return;
+        h16x8 fa[2][2][2], fb[2][2][2];     // [k16 half][32-row block][term]
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int p = 0; p < 2; ++p)
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    fa[ks][i][p] = *reinterpret_cast<lds_frag>(abase + ST * V2_STAGE + ks * (4 * V2_PLANE) + p * V2_PLANE + i * 512);
+                    fb[ks][i][p] = *reinterpret_cast<lds_frag>(bbase + ST * V2_STAGE + ks * (4 * V2_PLANE) + p * V2_PLANE + i * 512);
+                }
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {    // smallest terms first; consecutive MFMAs belong to four independent accumulator chains
+#pragma unroll
+            for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+                for (int ni = 0; ni < 2; ++ni) acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[ks][mi][1], fb[ks][ni][0], acc[mi][ni], 0, 0, 0);
+#pragma unroll
+            for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+                for (int ni = 0; ni < 2; ++ni) acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[ks][mi][0], fb[ks][ni][1], acc[mi][ni], 0, 0, 0);
+#pragma unroll
+            for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+                for (int ni = 0; ni < 2; ++ni) acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[ks][mi][0], fb[ks][ni][0], acc[mi][ni], 0, 0, 0);
+        }
+        __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);        // 8 DS reads (first k16 half)
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);    // 1 MFMA
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);    // 1 DS read (second half)
+        }
+        __builtin_amdgcn_sched_group_barrier(0x008, 16, 0);       // the rest
+    };
+    // step t reads stage t % 3; the DMA of step t + 2 goes into stage (t + 2) % 3 = the one step t - 1 read.
+    // vmcnt at the top of step t: everything OLDER than this wave's own pieces of step t + 1 must have landed.
+    auto step = [&](int t, auto st, auto st_next2) {
+        if (t + 1 < nk) v2_wait_vmcnt<NBLK>(); else v2_wait_vmcnt<0>();
+        v2_barrier();
+        if (t + 2 < nk) issue(decltype(st_next2)::value);
+        compute(st);
+    };
+    issue(0);
+    if (nk > 1) issue(1);
+    int t = 0;
+    for (; t + 2 < nk; t += 3) {
+        step(t, IC<0>{}, IC<2>{});
+        step(t + 1, IC<1>{}, IC<0>{});
+        step(t + 2, IC<2>{}, IC<1>{});
+    }
+    if (t < nk) { step(t, IC<0>{}, IC<2>{}); ++t; }
+    if (t < nk) { step(t, IC<1>{}, IC<0>{}); ++t; }
+    v2_barrier();                      // everybody is done reading: the ring is the caller's
+}
+
+
+// (2) 128 x 128 tiles of 256 threads, two independent workgroups per CU:
 // ---- the same pipeline as 128 x 128 tiles of 256 threads, TWO independent workgroups per CU ------------------------------------
 // Same operands, same planes, same arithmetic and summation order per accumulator as the 256 x 128 tile.  What changes is who
 // waits for whom: the eight waves of the big tile meet at ONE barrier per step (rocprofv3: 39 % of their time in
@@ -190,6 +343,28 @@ __global__ __launch_bounds__(V2S_THREADS, 2) void v2s_kernel(const void* As, con
     });
 }
 
+// loader / consumer form: 768 threads
+template <int MB>
+__global__ __launch_bounds__(V2L_THREADS, 3) void v2l_kernel(const void* As, const void* Bs, const float* rinv, const float* cinv,
+                                                             float* C, int M, int N, int K) {
+    extern __shared__ __attribute__((aligned(16))) char smem_c[];
+    f32x16 acc[2][2];
+    zero_acc(acc);
+    const int m0 = blockIdx.y * (MB * 64), n0 = blockIdx.x * 128;
+    gemm_tile_f16x2_v2l<MB>(As, m0 / 64, Bs, n0 / 64, K, smem_c, acc);
+    if ((int)(threadIdx.x >> 6) >= 2 * MB) return;
+    float* smem = reinterpret_cast<float*>(smem_c);
+    acc_to_lds(smem, acc);
+    __builtin_amdgcn_s_waitcnt(0xc07f);
+    for_each_row4(smem, [&](int r, int col, float4 v) {
+        const float ri = rinv[m0 + r];
+        const f32x4 ci = *(const gf32x4*)(cinv + n0 + col);
+        f32x4 o;
+        o[0] = ri * (ci[0] * v.x); o[1] = ri * (ci[1] * v.y); o[2] = ri * (ci[2] * v.z); o[3] = ri * (ci[3] * v.w);
+        *(gf32x4*)(C + (size_t)(m0 + r) * N + n0 + col) = o;
+    });
+}
+
 // first-generation tile, one scale per operand matrix
 __global__ __launch_bounds__(256, 2) void v1_kernel(const float* A, const _Float16* Bt, float* C, int M, int N, int K, float sa, float unscale) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -320,6 +495,32 @@ static int run_shape(int M, int N, int K, bool wide_rows) {
         const double tbig = M % 256 == 0 ? fl / time_it([&] { hipLaunchKernelGGL(v2_kernel<4>, dim3(N / 128, M / 256), dim3(V2_THREADS), V2_SMEM_BYTES, 0, As, Bs, rinv, cinv, C, M, N, K); }) / 1e9 : 0.0;
         printf("  gen-2 128x128 x 256 threads, 2 WG/CU : S=5 %.1f  S=4 %.1f  S=3 %.1f TF-eq (256x128 x 512 threads right after: %.1f) | elements differing from the 256x128 family %zu | unstable repeats %d\n",
                t5, t4s, t3s, tbig, bad, unstable5);
+    }
+    if (M % 256 == 0) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(v2l_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, V2_SMEM_BYTES);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(v2l_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, V2_SMEM_BYTES);
+        std::vector<float> cl((size_t)M * N), cr((size_t)M * N);
+        CK(hipMemset(C, 0, (size_t)M * N * 4));
+        hipLaunchKernelGGL(v2l_kernel<4>, dim3(N / 128, M / 256), dim3(V2L_THREADS), V2_SMEM_BYTES, 0, As, Bs, rinv, cinv, C, M, N, K);
+        CK(hipGetLastError());
+        CK(hipMemcpy(cl.data(), C, cl.size() * 4, hipMemcpyDeviceToHost));
+        size_t bad = 0; for (size_t i = 0; i < cl.size(); ++i) bad += cl[i] != c2[i];
+        CK(hipMemset(C, 0, (size_t)M * N * 4));
+        hipLaunchKernelGGL(v2l_kernel<2>, dim3(N / 128, M / 128), dim3(V2L_THREADS), V2_SMEM_BYTES, 0, As, Bs, rinv, cinv, C, M, N, K);
+        CK(hipMemcpy(cr.data(), C, cr.size() * 4, hipMemcpyDeviceToHost));
+        size_t bad2 = 0; for (size_t i = 0; i < cr.size(); ++i) bad2 += cr[i] != c2[i];
+        int unstable_l = 0;
+        for (int rep = 0; rep < 4; ++rep) {
+            CK(hipMemset(C, 0, (size_t)M * N * 4));
+            hipLaunchKernelGGL(v2l_kernel<4>, dim3(N / 128, M / 256), dim3(V2L_THREADS), V2_SMEM_BYTES, 0, As, Bs, rinv, cinv, C, M, N, K);
+            CK(hipMemcpy(cr.data(), C, cr.size() * 4, hipMemcpyDeviceToHost));
+            for (size_t i = 0; i < cr.size(); ++i) if (cr[i] != cl[i]) { ++unstable_l; break; }
+        }
+        const double tl = fl / time_it([&] { hipLaunchKernelGGL(v2l_kernel<4>, dim3(N / 128, M / 256), dim3(V2L_THREADS), V2_SMEM_BYTES, 0, As, Bs, rinv, cinv, C, M, N, K); }) / 1e9;
+        const double tb = fl / time_it([&] { hipLaunchKernelGGL(v2_kernel<4>, dim3(N / 128, M / 256), dim3(V2_THREADS), V2_SMEM_BYTES, 0, As, Bs, rinv, cinv, C, M, N, K); }) / 1e9;
+        const double tl2 = fl / time_it([&] { hipLaunchKernelGGL(v2l_kernel<4>, dim3(N / 128, M / 256), dim3(V2L_THREADS), V2_SMEM_BYTES, 0, As, Bs, rinv, cinv, C, M, N, K); }) / 1e9;
+        printf("  gen-2 256x128 loader/consumer (8 + 4 waves): %.1f TF-eq | all-waves-load right after: %.1f | loader/consumer again: %.1f | differing elements %zu (MB=2 form %zu) | unstable repeats %d\n",
+               tl, tb, tl2, bad, bad2, unstable_l);
     }
     printf("  gen-2 128x128 (MB=2) tile             : %.3f ms = %6.1f TF fp32-equivalent | worst per-row rel err %.3g | max|MB4 - MB2| on the sampled rows %.3g\n", t2, fl / t2 / 1e9, worst3, M % 256 == 0 ? d23 : -1.0);
     printf("  operand preparation: row split of A %.3f ms (%.2f TB/s of read+write), column scales + split of P^T %.3f ms\n", t_rows, 2.0 * M * K * 4 / t_rows / 1e9, t_cols);
