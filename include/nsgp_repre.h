@@ -175,15 +175,18 @@ int nsgp_project(const float* a, const float* proj, float* out, int rows, int co
  * Replaces BRNullSpaceRunner.compute_cov + update_cov,
  *   mmdet/engine/runner/nsrunner_roi_replay.py:876-916, 923-934:
  *   X = unfold(mean_batch(x), k, pad, stride) viewed [L x D];  C (+)= X^T X
- * without materialising X (implicit im2col).  x: [B,Cin,H,W]; cov: [D x D], D=Cin*kh*kw.
- * workspace: >= nsgp_cov_workspace_bytes (the zero-padded batch mean + one 128x128 slab per stream-K segment).
+ * x: [B,Cin,H,W]; cov: [D x D], D=Cin*kh*kw.  X is never materialised as fp32: narrow layers gather it tile by tile
+ * (implicit im2col); layers with D >= 512 on the fp16-split path write X^T ONCE as the pre-tiled, pre-scaled two-term fp16
+ * operand of the projection kernel (4 bytes per element, the size of the reference's unfold buffer) and contract it with
+ * that kernel's LDS-DMA tile.
+ * workspace: >= nsgp_cov_workspace_bytes (the zero-padded batch mean + split-K slabs + that operand where it is used).
  * accumulate=0 is the reference's first call (assign), 1 the later ones (add).
  * ------------------------------------------------------------------------ */
 size_t nsgp_cov_workspace_bytes(int cin, int h, int w, int kh, int kw, int sh, int sw, int ph, int pw);
 /* Process-wide choice of the SYRK's matrix-core path: 0 = fp32 MFMA, 2 = two-term fp16 split (three fp16 MFMAs per
  * fp32-equivalent product, one power-of-two scale per layer found from the batch mean; fp32-level error), 1 (default) = the
- * split for layers large enough to repay its two extra tiny launches.  Returns the previous setting.  The workspace size
- * covers both paths. */
+ * split for layers large enough to repay its two extra tiny launches; 3 = always the split, restricted to its
+ * first-generation (gather) kernel.  Returns the previous setting.  The workspace size covers every path. */
 int nsgp_cov_set_split_mfma(int mode);
 int nsgp_cov_accumulate_conv2d(const float* x, int batch, int cin, int h, int w, int kh, int kw,
                                int sh, int sw, int ph, int pw, float* cov, int accumulate,

@@ -20,6 +20,7 @@
 #include "common.hpp"
 #include "gemm_core.hpp"
 #include "gemm_f16x2.hpp"
+#include "gemm_f16x2_v2.hpp"
 
 namespace nsgp {
 
@@ -336,8 +337,145 @@ __global__ __launch_bounds__(256, 2) void nsgp_cov_syrk_f16_kernel(const float* 
     }
 }
 
+// ---- second generation of the fp16-split SYRK (wide layers, D >= 512) -------------------------------------------------------------
+// The first-generation kernel above gathers the implicit X^T tile by tile: every element is fetched (4-byte-aligned 16-byte
+// loads at best) and split by each of the D / 128 tiles that use its row, and the kernel is bound by those memory instructions
+// (fpn 3x3: 2.2 ms for 357 GFLOP of upper triangle).  With 288 GB of HBM the reference's own answer -- materialise the unfold -- is
+// affordable, if it is materialised ONCE in the form the matrix cores want: X^T as the pre-tiled, pre-scaled two-term fp16
+// operand of gemm_f16x2_v2.hpp ([d/64][l/8][term][d%64][8 halves], 4 bytes per element: 619 MB for the fpn 3x3 at 800 x 1344,
+// exactly the size of the reference's fp32 unfold buffer).  Then C = X^T X is the projection kernel's tile -- LDS-DMA loaders,
+// consumers with nothing but LDS reads and MFMAs -- over the 256 x 128 tiles that touch the upper triangle, split-K into S
+// aligned ranges (workgroups of one range walk the same columns of X^T at the same time, so its row panels are shared through
+// L2), slab per (tile, range), and an ordered reduce that unscales, keeps diagonal tiles bit-symmetric and mirrors.
+//   nsgp_cov_im2col_split_kernel -> nsgp_cov_syrk_v2_kernel -> nsgp_cov_reduce_v2_kernel
+__host__ __device__ __forceinline__ int cov2_pad_d(int D) { return (D + 127) / 128 * 128; }       // rows: whole 128-row tiles
+__host__ __device__ __forceinline__ int cov2_pad_l(int L) { return (L + V2_BK - 1) / V2_BK * V2_BK; }
+// tiles: row tile r covers 64-row blocks [4r, 4r + mb), mb = 4 or 2 (remainder); column tile c blocks [2c, 2c + 2); a tile is
+// needed when its columns reach the row tile's first row: 2c >= 4r.
+__host__ __device__ __forceinline__ int cov2_tiles(int Dp) {
+    const int nblk = Dp / 64;
+    int n = 0;
+    for (int rb0 = 0; rb0 < nblk; rb0 += 4) n += (nblk - rb0) / 2;
+    return n;
+}
+__host__ __device__ __forceinline__ void cov2_tile_of(int t, int Dp, int& rb0, int& cb0, int& mb) {
+    const int nblk = Dp / 64;
+    rb0 = 0;
+    while (t >= (nblk - rb0) / 2) { t -= (nblk - rb0) / 2; rb0 += 4; }
+    cb0 = rb0 + 2 * t;
+    mb = nblk - rb0 >= 4 ? 4 : 2;
+}
+__host__ __device__ __forceinline__ int cov2_tile_index(int rb0, int cb0, int Dp) {
+    const int nblk = Dp / 64;
+    int n = 0;
+    for (int r = 0; r < rb0; r += 4) n += (nblk - r) / 2;
+    return n + (cb0 - rb0) / 2;
+}
+
+// one wave = one (64-row block, l-octet): lane = row d; 8 consecutive output positions per lane -> the two 16-byte pieces
+__global__ __launch_bounds__(256) void nsgp_cov_im2col_split_kernel(const float* __restrict__ xm, ConvGeom g, int Dp, int Lp,
+                                                                    const unsigned* __restrict__ amax, void* __restrict__ xt) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int o = blockIdx.x * 4 + wave;                 // l-octet
+    if (o * 8 >= Lp) return;
+    const int d = blockIdx.y * 64 + lane;
+    const float scale = f2_scale_from_amax_bits(*amax);
+    f32x4 r[2];
+    r[0] = f32x4{0, 0, 0, 0};
+    r[1] = f32x4{0, 0, 0, 0};
+    if (d < g.D && o * 8 < g.L) {
+        const Patch8 pc = patch8(g, 1.0f / (float)g.Wo, o * 8, g.L);
+        stage8(xm, im2col_rowbase1(g, d), pc, r);
+    }
+    v2_store_pieces(xt, d, o, Lp, r[0], r[1], scale);
+    (void)Dp;
+}
+
+__global__ __launch_bounds__(V2L_THREADS, 3) void nsgp_cov_syrk_v2_kernel(const void* __restrict__ xt, int Dp, int Lp, int S, int steps_per_split,
+                                                                         float* __restrict__ slabs) {
+    extern __shared__ __attribute__((aligned(16))) char smem_c[];
+    const int tile = blockIdx.x / S, sp = blockIdx.x - tile * S;
+    int rb0, cb0, mb;
+    cov2_tile_of(tile, Dp, rb0, cb0, mb);
+    const int nk = Lp / V2_BK;
+    const int s0 = sp * steps_per_split;
+    const int ns = min(steps_per_split, nk - s0);
+    f32x16 acc[2][2];
+    zero_acc(acc);
+    if (ns > 0) {
+        if (mb == 4) gemm_tile_f16x2_v2l<4>(xt, rb0, xt, cb0, Lp, smem_c, acc, s0, ns);
+        else gemm_tile_f16x2_v2l<2>(xt, rb0, xt, cb0, Lp, smem_c, acc, s0, ns);
+    }
+    if ((int)(threadIdx.x >> 6) >= 2 * mb) return;
+    float* smem = reinterpret_cast<float*>(smem_c);
+    float* out = slabs + (size_t)blockIdx.x * (256 * 128);
+    acc_to_lds(smem, acc);
+    __builtin_amdgcn_s_waitcnt(0xc07f);
+    for_each_row4(smem, [&](int r, int col, float4 v) {
+        f32x4 q;
+        q[0] = v.x; q[1] = v.y; q[2] = v.z; q[3] = v.w;
+        *(gf32x4*)(out + r * 128 + col) = q;
+    });
+}
+
 constexpr int RED_LD = BN + 1;
 constexpr int RED_MAX_ROWS = 64;
+
+// grid (128 x 128 upper-triangle tiles of C, bands): sums the S range slabs of the parent 256 x 128 tile in range order.
+__global__ __launch_bounds__(256) void nsgp_cov_reduce_v2_kernel(const float* __restrict__ slabs, int D, int Dp, int S, int rows,
+                                                                 float* __restrict__ cov, int accumulate, const unsigned* __restrict__ amax) {
+    __shared__ float tile[RED_MAX_ROWS * RED_LD];
+    const float sc = f2_scale_from_amax_bits(*amax);
+    const float unscale = (1.0f / sc) * (1.0f / sc);
+    const int nb = Dp / 128;
+    int ti, tj;
+    tile_of(blockIdx.x, nb, ti, tj);
+    const int r0 = blockIdx.y * rows;
+    const int m0 = ti * 128, n0 = tj * 128;
+    if (m0 + r0 >= D) return;
+    const int rb0 = (2 * ti) / 4 * 4, sub = (2 * ti - rb0) / 2;          // parent row tile and which 128-row half of its slab
+    const float* base = slabs + (size_t)cov2_tile_index(rb0, 2 * tj, Dp) * S * (256 * 128) + (size_t)sub * 128 * 128;
+    if (ti != tj) {
+        for (int idx = threadIdx.x; idx < rows * 32; idx += 256) {
+            const int r = idx >> 5, c4 = (idx & 31) * 4;
+            const size_t off = (size_t)(r0 + r) * 128 + c4;
+            f32x4 sum = *(const gf32x4*)(base + off);
+            for (int s = 1; s < S; ++s) {
+                const f32x4 v = *(const gf32x4*)(base + (size_t)s * (256 * 128) + off);
+                sum[0] += v[0]; sum[1] += v[1]; sum[2] += v[2]; sum[3] += v[3];
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) tile[r * RED_LD + c4 + e] = sum[e] * unscale;
+        }
+    } else {    // diagonal tile: (i,j) and (j,i) hold the same products in a different order -- take the upper triangle for both
+        for (int idx = threadIdx.x; idx < rows * 128; idx += 256) {
+            const int r = idx >> 7, c = idx & 127, ra = r0 + r;
+            const size_t off = (c >= ra) ? (size_t)ra * 128 + c : (size_t)c * 128 + ra;
+            float sum = as_global(base)[off];
+            for (int s = 1; s < S; ++s) sum += as_global(base)[(size_t)s * (256 * 128) + off];
+            tile[r * RED_LD + c] = sum * unscale;
+        }
+    }
+    __syncthreads();
+    for (int idx = threadIdx.x; idx < rows * 128; idx += 256) {
+        const int r = idx >> 7, c = idx & 127;
+        if (m0 + r0 + r < D && n0 + c < D) {
+            const long o = (long)(m0 + r0 + r) * D + n0 + c;
+            const float v = tile[r * RED_LD + c];
+            as_global(cov)[o] = accumulate ? (as_global(cov)[o] + v) : v;
+        }
+    }
+    if (ti != tj) {
+        for (int idx = threadIdx.x; idx < rows * 128; idx += 256) {
+            const int c = idx / rows, r = idx - c * rows;
+            if (m0 + r0 + r < D && n0 + c < D) {
+                const long o = (long)(n0 + c) * D + m0 + r0 + r;
+                const float v = tile[r * RED_LD + c];
+                as_global(cov)[o] = accumulate ? (as_global(cov)[o] + v) : v;
+            }
+        }
+    }
+}
 
 // grid (tiles, R): workgroup (t, y) owns rows [y*rows, (y+1)*rows) of upper-triangle tile t: sums that band over
 // the tile's segments in workgroup order, writes it and its mirror.  R grows when there are few tiles -- a D=64
@@ -418,6 +556,7 @@ struct CovPlan {
     long tiles, G, P;
 };
 
+static int g_cov_gen2 = 1;     // fp16-split path: wide layers (D >= 512) take the materialised-operand / LDS-DMA generation; 0 keeps the gather kernel (tests, A/B)
 static int g_cov_split = 1;    // 0: fp32 MFMA SYRK, 1: auto (default: the fp16 split where the extra amax launch pays), 2: always the fp16 split
 
 static CovPlan cov_plan(int D, int L, int kstep) {
@@ -432,6 +571,29 @@ static CovPlan cov_plan(int D, int L, int kstep) {
 
 static size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
 
+// second-generation split path: wide layers only (the padding to 128-row tiles and the 619 MB-class operand do not pay below)
+struct Cov2Plan {
+    bool use;
+    int Dp, Lp, tiles, S, steps;
+    size_t xt_bytes, slab_bytes;
+};
+static Cov2Plan cov2_plan(int D, int L) {
+    Cov2Plan q{};
+    q.use = D >= 512 && D % 64 == 0 && L >= 256;
+    if (!q.use) return q;
+    q.Dp = cov2_pad_d(D);
+    q.Lp = cov2_pad_l(L);
+    q.tiles = cov2_tiles(q.Dp);
+    const int nk = q.Lp / V2_BK;
+    int S = (512 + q.tiles - 1) / q.tiles;                       // ~two rounds of one-workgroup CUs
+    S = std::max(1, std::min(S, nk / 8));                        // at least 8 steps per range
+    q.steps = (nk + S - 1) / S;
+    q.S = (nk + q.steps - 1) / q.steps;
+    q.xt_bytes = align256(v2_operand_bytes(q.Dp, q.Lp));
+    q.slab_bytes = (size_t)q.tiles * q.S * 256 * 128 * 4;
+    return q;
+}
+
 }  // namespace nsgp
 
 using namespace nsgp;
@@ -443,7 +605,10 @@ extern "C" size_t nsgp_cov_workspace_bytes(int cin, int h, int w, int kh, int kw
     if (Ho <= 0 || Wo <= 0) return 0;
     const int D = cin * kh * kw;
     const CovPlan p16 = cov_plan(D, Ho * Wo, F2_BK), p32 = cov_plan(D, Ho * Wo, BK);     // enough for either path
-    return align256((size_t)cin * Hp * Wp * 4) + (size_t)(p32.tiles + std::max(p16.P, p32.P)) * BM * BN * 4 + 256;
+    const Cov2Plan q = cov2_plan(D, Ho * Wo);
+    const size_t slabs1 = (size_t)(p32.tiles + std::max(p16.P, p32.P)) * BM * BN * 4;
+    // [batch-mean image][slabs (either generation)][gen-2: the materialised split X^T][amax word]
+    return align256((size_t)cin * Hp * Wp * 4) + align256(std::max(slabs1, q.use ? q.slab_bytes : (size_t)0)) + (q.use ? q.xt_bytes : 0) + 256;
 }
 
 extern "C" int nsgp_cov_accumulate_conv2d(const float* x, int batch, int cin, int h, int w, int kh, int kw, int sh,
@@ -461,6 +626,10 @@ extern "C" int nsgp_cov_accumulate_conv2d(const float* x, int batch, int cin, in
     const CovPlan p32 = cov_plan(g.D, g.L, BK);
     const bool split = g_cov_split == 2 || (g_cov_split == 1 && p32.G >= 10000);
     const CovPlan p = cov_plan(g.D, g.L, split ? F2_BK : BK);
+    const Cov2Plan q = cov2_plan(g.D, g.L);
+    const CovPlan p16 = cov_plan(g.D, g.L, F2_BK);
+    const size_t slabs1 = (size_t)(p32.tiles + std::max(p16.P, p32.P)) * BM * BN * 4;
+    void* xt = static_cast<char*>(workspace) + align256((size_t)cin * Hp * Wp * 4) + align256(std::max(slabs1, q.use ? q.slab_bytes : (size_t)0));
     float* xm = static_cast<float*>(workspace);
     float* slabs = reinterpret_cast<float*>(static_cast<char*>(workspace) + align256((size_t)cin * Hp * Wp * 4));
     unsigned* amax = reinterpret_cast<unsigned*>(static_cast<char*>(workspace) + need - 256);
@@ -473,6 +642,21 @@ extern "C" int nsgp_cov_accumulate_conv2d(const float* x, int batch, int cin, in
         NSGP_HIP(hipMemsetAsync(amax, 0, sizeof(unsigned), stream));
         hipLaunchKernelGGL(nsgp_amax_kernel, dim3((unsigned)std::min<long>(512, (n_img / 4 + 255) / 256 + 1)), dim3(256), 0, stream, xm, n_img, amax);
         NSGP_LAUNCH_CHECK();
+        if (q.use && g_cov_gen2) {
+            hipLaunchKernelGGL(nsgp_cov_im2col_split_kernel, dim3((unsigned)((q.Lp / 8 + 3) / 4), (unsigned)(q.Dp / 64)), dim3(256), 0, stream,
+                               xm, g, q.Dp, q.Lp, amax, xt);
+            NSGP_LAUNCH_CHECK();
+            NSGP_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(nsgp_cov_syrk_v2_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, V2_SMEM_BYTES));
+            hipLaunchKernelGGL(nsgp_cov_syrk_v2_kernel, dim3((unsigned)(q.tiles * q.S)), dim3(V2L_THREADS), V2_SMEM_BYTES, stream, xt, q.Dp, q.Lp, q.S, q.steps, slabs);
+            NSGP_LAUNCH_CHECK();
+            const int nb128 = q.Dp / 128;
+            const long t128 = (long)nb128 * (nb128 + 1) / 2;
+            int bands2 = 2;
+            while (bands2 < 32 && t128 * bands2 < 256) bands2 *= 2;
+            hipLaunchKernelGGL(nsgp_cov_reduce_v2_kernel, dim3((unsigned)t128, bands2), dim3(256), 0, stream, slabs, g.D, q.Dp, q.S, 128 / bands2, cov, accumulate, amax);
+            NSGP_LAUNCH_CHECK();
+            return NSGP_OK;
+        }
         NSGP_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(nsgp_cov_syrk_f16_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, F2_SMEM_BYTES));
         hipLaunchKernelGGL(nsgp_cov_syrk_f16_kernel, dim3((unsigned)p.P), dim3(THREADS), F2_SMEM_BYTES, stream, xm, g, p.nk, p.G, amax, slabs);
     } else {
@@ -489,8 +673,10 @@ extern "C" int nsgp_cov_accumulate_conv2d(const float* x, int batch, int cin, in
 }
 
 extern "C" int nsgp_cov_set_split_mfma(int mode) {
-    const int prev = g_cov_split;
-    g_cov_split = mode < 0 ? 0 : (mode > 2 ? 2 : mode);
+    // 0: fp32 MFMA; 1: auto (default); 2: always the fp16 split; 3: always the split, first-generation (gather) kernel only
+    const int prev = g_cov_gen2 ? g_cov_split : 3;
+    g_cov_gen2 = mode != 3;
+    g_cov_split = mode < 0 ? 0 : (mode >= 2 ? 2 : mode);
     return prev;
 }
 

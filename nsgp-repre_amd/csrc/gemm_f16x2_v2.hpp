@@ -95,12 +95,14 @@ constexpr int V2L_THREADS = 768;
 
 template <int MB>
 __device__ __forceinline__ void gemm_tile_f16x2_v2l(const void* __restrict__ Asplit, int a_block0, const void* __restrict__ Bsplit,
-                                                    int b_block0, int K, char* smem, f32x16 (&acc)[2][2]) {
+                                                    int b_block0, int K, char* smem, f32x16 (&acc)[2][2], int step0 = 0, int nsteps = -1) {
+    // K = the operands' full contraction length (it sets the block stride); the tile contracts k32 steps [step0, step0 + nsteps)
+    // (default: all of them) -- split-K callers give each workgroup a range.
     static_assert(MB == 2 || MB == 4, "MB");
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const size_t blk = (size_t)K * 256;
-    const int nk = K / V2_BK;
+    const int nk = nsteps < 0 ? K / V2_BK : nsteps;
     if (wave >= 8) {
         // ------------------------------------------------------------------ loader
         constexpr int NPIECE = 2 * (MB + V2_NB);
@@ -108,10 +110,10 @@ __device__ __forceinline__ void gemm_tile_f16x2_v2l(const void* __restrict__ Asp
         unsigned long long src[V2_MB_MAX + V2_NB];
 #pragma unroll
         for (int b = 0; b < V2_MB_MAX; ++b)
-            src[b] = v2_uniform((unsigned long long)(uintptr_t)Asplit + (size_t)(a_block0 + (b < MB ? b : 0)) * blk + (size_t)l * (2 * V2_PLANE));
+            src[b] = v2_uniform((unsigned long long)(uintptr_t)Asplit + (size_t)(a_block0 + (b < MB ? b : 0)) * blk + (size_t)step0 * V2_STEP + (size_t)l * (2 * V2_PLANE));
 #pragma unroll
         for (int b = 0; b < V2_NB; ++b)
-            src[V2_MB_MAX + b] = v2_uniform((unsigned long long)(uintptr_t)Bsplit + (size_t)(b_block0 + b) * blk + (size_t)l * (2 * V2_PLANE));
+            src[V2_MB_MAX + b] = v2_uniform((unsigned long long)(uintptr_t)Bsplit + (size_t)(b_block0 + b) * blk + (size_t)step0 * V2_STEP + (size_t)l * (2 * V2_PLANE));
         const unsigned voff = lane * 16;
         const unsigned my_planes = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(lds_char*)smem + l * (2 * V2_PLANE));
         auto issue = [&](int stage) {

@@ -137,7 +137,9 @@ def cov_accumulate_conv2d(x: torch.Tensor, kernel_size, stride, padding, cov: to
 
 def cov_set_split_mfma(mode: int) -> int:
     """Select the covariance SYRK's matrix-core path: 0 = fp32 MFMA, 1 = auto (default: the two-term fp16 split for layers
-    large enough to repay its extra launches), 2 = always the split.  Returns the previous setting."""
+    large enough to repay its extra launches), 2 = always the split, 3 = always the split but only its first-generation
+    (gather) kernel -- by default layers with D >= 512 take the second generation (materialised pre-tiled operand, LDS-DMA
+    tiles, split-K).  Returns the previous setting."""
     return int(_lib.load_library().nsgp_cov_set_split_mfma(int(mode)))
 
 

@@ -305,10 +305,15 @@ def test_g3_covariance_vs_golden(N, dev, golden_dir):
 
 @pytest.mark.parametrize("cin,k,s,p,hw,B", [(64, (1, 1), (1, 1), (0, 0), (50, 84), 2), (32, (3, 3), (1, 1), (1, 1), (25, 42), 1),
                                             (16, (3, 3), (2, 2), (1, 1), (50, 84), 2), (3, (7, 7), (2, 2), (3, 3), (64, 96), 1),
-                                            (256, (1, 1), (1, 1), (0, 0), (13, 21), 1)])
-@pytest.mark.parametrize("mode", [0, 2])
+                                            (256, (1, 1), (1, 1), (0, 0), (13, 21), 1),
+                                            (64, (3, 3), (1, 1), (1, 1), (25, 42), 2),      # D = 576 = 4.5 x 128: padded rows + a 128-row remainder tile
+                                            (512, (1, 1), (1, 1), (0, 0), (13, 21), 1),     # D = 512, L = 273 (padded to 288)
+                                            (128, (3, 3), (2, 2), (1, 1), (50, 84), 1)])    # D = 1152, stride 2
+@pytest.mark.parametrize("mode", [0, 2, 3])
 def test_covariance_vs_oracle_mid_sizes(N, dev, cin, k, s, p, hw, B, mode):
-    """Both matrix-core paths of the SYRK (0 = fp32 MFMA, 2 = two-term fp16 split forced; the default picks by size)."""
+    """All matrix-core paths of the SYRK: 0 = fp32 MFMA; 2 = two-term fp16 split forced (layers with D >= 512 take its second
+    generation: materialised pre-tiled operand + LDS-DMA tiles, split-K); 3 = the split's first generation (gather kernel) for
+    every layer.  The default picks by size."""
     from nsgp_repre_amd import ops
     x = torch.randn(B, cin, *hw, generator=torch.Generator().manual_seed(cin)).abs()
     ref = O.cov_conv2d(x, k, s, p)
@@ -335,12 +340,12 @@ _TRUE_SIZE = {   # (cin, kernel, stride, pad, H, W) at an 800 x 1344 padded imag
 _cov_true = {}
 
 
-@pytest.mark.parametrize("mode", [0, 2])
+@pytest.mark.parametrize("mode", [0, 2, 3])
 @pytest.mark.parametrize("name", list(_TRUE_SIZE))
 def test_covariance_at_true_size(N, dev, name, mode):
     """full-size covariance parity was unpinned (tests stopped at 64 x 96 inputs; the 7 x 7 stem differed from
     rocBLAS by 1.78e-5 with nobody knowing which side was off).  Three R-50-FPN layers at 800 x 1344, both matrix-core paths
-    (0 = fp32 MFMA, 2 = two-term fp16 split), channels spanning three decades, against (i) an fp64 product of the materialised
+    (0 = fp32 MFMA, 2 = two-term fp16 split: second generation for D >= 512, 3 = its first-generation gather kernel), channels spanning three decades, against (i) an fp64 product of the materialised
     unfold on the GPU -- tensor-max and PER ROW -- and (ii) the ORACLE (the reference's fp32 unfold + mm on the CPU), whose own
     distance from fp64 is measured beside ours; the adaptive elbow (an INTEGER that decides the projector's rank) must be
     the same for the fp32 and the fp16-split covariance.  NSGP_REPORT_DIR collects the numbers (profiles/r02/covariance_true_size.json)."""
@@ -364,7 +369,7 @@ def test_covariance_at_true_size(N, dev, name, mode):
     if key not in _cov_true:
         _cov_true[key] = O.cov_conv2d(x, (k, k), (st, st), (pd, pd))                   # the oracle, once per layer
     orc = _cov_true[key].to(dev)
-    rec = dict(layer=name, path={0: "f32", 2: "f16x2"}[mode], L=int((H + 2 * pd - k) // st + 1) * int((W + 2 * pd - k) // st + 1), D=cin * k * k,
+    rec = dict(layer=name, path={0: "f32", 2: "f16x2", 3: "f16x2-gather"}[mode], L=int((H + 2 * pd - k) // st + 1) * int((W + 2 * pd - k) // st + 1), D=cin * k * k,
                ours_vs_fp64_tensor_rel=_rel(cov, ref64), ours_vs_fp64_row_rel=_row_rel(cov, ref64),
                oracle_vs_fp64_tensor_rel=_rel(orc, ref64), oracle_vs_fp64_row_rel=_row_rel(orc, ref64),
                ours_vs_oracle_tensor_rel=_rel(cov, orc), ours_vs_oracle_row_rel=_row_rel(cov, orc))

@@ -93,6 +93,38 @@ def test_cal_fea_in_matches_oracle_and_accumulates_previous_task(N, dev):
     assert not any(len(m._forward_hooks) for m in net.modules())   # hooks removed
 
 
+def test_covariance_hooks_under_bf16_activations(N, dev):
+    """configs[4] ("fp32 covariance / bf16 activations"): when the hooked forward runs under bf16 autocast the hooks see bf16
+    inputs.  The covariance stays fp32: each hook widens its input exactly (bf16 -> fp32 is lossless), so the result must equal
+    -- bit for bit -- the fp32 covariance of the very bf16 values the layers consumed, and the files keep dtype float32."""
+    torch.manual_seed(2)
+    net = Net().to(dev).eval()
+    batches = [torch.randn(2, 3, 20, 28, device=dev) for _ in range(2)]
+    ignore = N.runner.full_ignore_keys(["rpn", "roi_head"])
+    seen = {}
+    hs = [m.register_forward_hook(lambda mod, i, o, n=n: seen.setdefault(n, []).append(i[0].detach().clone()))
+          for n, m in net.named_modules() if isinstance(m, (nn.Conv2d, nn.Linear)) and not n.startswith("rpn")]
+
+    def fwd(model, batch):
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            model(batch)
+    cov = N.runner.cal_fea_in(net, batches, ignore, forward=fwd)
+    for h in hs:
+        h.remove()
+    from nsgp_repre_amd import ops
+    assert all(v.dtype == torch.float32 for v in cov.values())
+    for n, m in net.named_modules():
+        if n + ".weight" not in cov:
+            continue
+        want = None
+        for x in seen[n]:
+            xf = x.float().contiguous()
+            want = (ops.cov_accumulate_conv2d(xf, m.kernel_size, m.stride, m.padding, want) if isinstance(m, nn.Conv2d)
+                    else ops.cov_accumulate_linear(xf, want))
+        assert torch.equal(cov[n + ".weight"], want), n
+    assert any(x.dtype == torch.bfloat16 for xs in seen.values() for x in xs)      # the hooks did see bf16 activations
+
+
 def test_prototype_replay_head_from_files(N, dev, golden_dir):
     """rois_etc.pth -> bank + mask.pth in the next work dir; then mask.pth replayed gives the same bank."""
     g = np.load(os.path.join(golden_dir, "g4_prototypes.npz"))
