@@ -163,7 +163,7 @@ def once_per_task_units(N, dev):
              for n in names[:3]}
     out["eigens_and_transforms_r50"] = {
         "get_eigens_ms": (t1 - t0) * 1e3, "get_transforms_ms": (t2 - t1) * 1e3, "layers": len(layers),
-        "eigensolver": "torch.linalg.eigh (rocSOLVER syevd) per layer -- a library call", "projector_kernel": "nsgp_projector_kernel (HIP SYRK)",
+        "eigensolver": "torch.linalg.eigh (rocSOLVER syevd, a library call), equal-width layers batched 16 per call", "projector_kernel": "nsgp_projector_kernel (HIP SYRK)",
         "note": "the reference runs torch.svd on every rank, twice (runner:554-555); under DDP the product shards the layers over the ranks (runner/dist.py)",
         "example_ranks_removed": ranks}
     opt.close()
