@@ -585,9 +585,18 @@ static Cov2Plan cov2_plan(int D, int L) {
     q.Lp = cov2_pad_l(L);
     q.tiles = cov2_tiles(q.Dp);
     const int nk = q.Lp / V2_BK;
-    int S = (512 + q.tiles - 1) / q.tiles;                       // ~two rounds of one-workgroup CUs
-    S = std::max(1, std::min(S, nk / 8));                        // at least 8 steps per range
-    q.steps = (nk + S - 1) / S;
+    // split-K ranges: one workgroup per CU at a time, so the launch takes ceil(tiles * S / 256) rounds of (steps per range + a
+    // fixed prologue / epilogue cost of ~20 steps), and every range adds a 128 KiB slab per tile to write and reduce (~0.055
+    // steps each).  Take the cheapest S <= 32 with at least 8 steps per range, preferring fewer ranges when within 5 %.
+    // (fpn 3x3: 90 tiles x 2100 steps -> S = 5; layer1 3x3: 9 tiles x 2100 -> S = 28; layer3 3x3: 90 x 132 -> S = 2.)
+    int bestS = 1;
+    double best = -1.0;
+    for (int S = 1; S <= 32 && nk / S >= 8; ++S) {
+        const long rounds = ((long)q.tiles * S + 255) / 256;
+        const double cost = (double)rounds * ((nk + S - 1) / S + 20) + 0.055 * S * q.tiles;
+        if (best < 0 || cost < best * 0.95) { best = cost; bestS = S; }
+    }
+    q.steps = (nk + bestS - 1) / bestS;
     q.S = (nk + q.steps - 1) / q.steps;
     q.xt_bytes = align256(v2_operand_bytes(q.Dp, q.Lp));
     q.slab_bytes = (size_t)q.tiles * q.S * 256 * 128 * 4;
@@ -624,9 +633,10 @@ extern "C" int nsgp_cov_accumulate_conv2d(const float* x, int batch, int cin, in
     ConvGeom g{cin * kh * kw, Ho * Wo, Wo, kh, kw, sh, sw, Hp, Wp};
     // the split path costs two extra tiny launches (clear + amax): measured worth it from ~10^4 (tile, k32-step) units on
     const CovPlan p32 = cov_plan(g.D, g.L, BK);
-    const bool split = g_cov_split == 2 || (g_cov_split == 1 && p32.G >= 10000);
-    const CovPlan p = cov_plan(g.D, g.L, split ? F2_BK : BK);
     const Cov2Plan q = cov2_plan(g.D, g.L);
+    // auto: the split pays from ~10^4 (tile, k32-step) units on, and -- with its second generation -- on every wide layer
+    const bool split = g_cov_split == 2 || (g_cov_split == 1 && (p32.G >= 10000 || (q.use && g_cov_gen2)));
+    const CovPlan p = cov_plan(g.D, g.L, split ? F2_BK : BK);
     const CovPlan p16 = cov_plan(g.D, g.L, F2_BK);
     const size_t slabs1 = (size_t)(p32.tiles + std::max(p16.P, p32.P)) * BM * BN * 4;
     void* xt = static_cast<char*>(workspace) + align256((size_t)cin * Hp * Wp * 4) + align256(std::max(slabs1, q.use ? q.slab_bytes : (size_t)0));
