@@ -119,6 +119,12 @@ __device__ __forceinline__ void adam_elem(float& p, float& g, float& m, float& v
     if (projected) u = upd; else p = p + upd;
 }
 
+// Gradients may be views into a flat bucket (DDP's gradient_as_bucket_view: parameters packed back to back, so one odd-sized
+// bias shifts everything behind it off the 16-byte grid).  Parameters and optimizer state are whole allocations and stay
+// aligned, so only the gradient stream uses 4-byte-aligned 16-byte accesses; the kernel keeps its float4 shape.
+typedef float f32x4_a4 __attribute__((ext_vector_type(4), aligned(4)));
+typedef __attribute__((address_space(1))) f32x4_a4 gf32x4_a4;
+
 // Row bookkeeping of a band workgroup: a thread walks its elements in steps of `stride` and needs the band-local row of
 // each (cols % 4 == 0, so a float4 never straddles rows).  One division per thread up front, increments afterwards.
 struct RowWalk {
@@ -151,7 +157,7 @@ __global__ __launch_bounds__(256) void nsgp_update_kernel(const ChunkDev* __rest
     const long span = band ? 8L * T.cols : (long)CHUNK;
     const long end = (c.start + span < T.numel) ? c.start + span : T.numel;
     const bool proj = T.projected != 0;
-    const bool vec = (((uintptr_t)T.p | (uintptr_t)gp | (uintptr_t)T.s0 | (uintptr_t)T.s1 | (uintptr_t)T.s2 |
+    const bool vec = (((uintptr_t)T.p | ((uintptr_t)gp & 3u) | (uintptr_t)T.s0 | (uintptr_t)T.s1 | (uintptr_t)T.s2 |
                        (uintptr_t)T.u) & 15u) == 0;
     // the mutated gradient is the GEMM's A operand unless a non-Nesterov momentum buffer is
     bool wg = h.write_grad != 0;
@@ -179,8 +185,8 @@ __global__ __launch_bounds__(256) void nsgp_update_kernel(const ChunkDev* __rest
         if (band) rw.init((long)threadIdx.x * 4, 256 * 4, T.cols);
         for (; i + 3 < end; i += 256 * 4) {
             float4 p4 = *reinterpret_cast<const float4*>(T.p + i);
-            float4 g4 = *reinterpret_cast<const float4*>(gp + i);
-            float pv[4] = {p4.x, p4.y, p4.z, p4.w}, gv[4] = {g4.x, g4.y, g4.z, g4.w};
+            const f32x4_a4 g4 = *(const gf32x4_a4*)(gp + i);
+            float pv[4] = {p4.x, p4.y, p4.z, p4.w}, gv[4] = {g4[0], g4[1], g4[2], g4[3]};
             if (OPT == NSGP_OPT_SGD) {
                 float bv[4] = {0, 0, 0, 0};
                 if (h.momentum != 0.0f) {
@@ -195,7 +201,7 @@ __global__ __launch_bounds__(256) void nsgp_update_kernel(const ChunkDev* __rest
                 }
                 if (h.momentum != 0.0f) *reinterpret_cast<float4*>(T.s0 + i) = make_float4(bv[0], bv[1], bv[2], bv[3]);
                 if (wg && (h.weight_decay != 0.0f || (h.momentum != 0.0f && h.nesterov)))
-                    *reinterpret_cast<float4*>(gp + i) = make_float4(gv[0], gv[1], gv[2], gv[3]);
+                    *(gf32x4_a4*)(gp + i) = f32x4_a4{gv[0], gv[1], gv[2], gv[3]};
                 if (!proj) *reinterpret_cast<float4*>(T.p + i) = make_float4(pv[0], pv[1], pv[2], pv[3]);
             } else {
                 float4 m4 = *reinterpret_cast<const float4*>(T.s0 + i);
@@ -212,7 +218,7 @@ __global__ __launch_bounds__(256) void nsgp_update_kernel(const ChunkDev* __rest
                 *reinterpret_cast<float4*>(T.s0 + i) = make_float4(mv[0], mv[1], mv[2], mv[3]);
                 *reinterpret_cast<float4*>(T.s1 + i) = make_float4(vv[0], vv[1], vv[2], vv[3]);
                 if (h.amsgrad) *reinterpret_cast<float4*>(T.s2 + i) = make_float4(xv[0], xv[1], xv[2], xv[3]);
-                if (wg && h.weight_decay != 0.0f) *reinterpret_cast<float4*>(gp + i) = make_float4(gv[0], gv[1], gv[2], gv[3]);
+                if (wg && h.weight_decay != 0.0f) *(gf32x4_a4*)(gp + i) = f32x4_a4{gv[0], gv[1], gv[2], gv[3]};
                 if (proj) *reinterpret_cast<float4*>(T.u + i) = make_float4(uv[0], uv[1], uv[2], uv[3]);
                 else *reinterpret_cast<float4*>(T.p + i) = make_float4(pv[0], pv[1], pv[2], pv[3]);
             }
@@ -258,14 +264,15 @@ __global__ __launch_bounds__(256) void nsgp_update_kernel(const ChunkDev* __rest
     }
     __syncthreads();
     const float* __restrict__ Asrc = (OPT == NSGP_OPT_SGD) ? (a_is_buf ? T.s0 : gp) : T.u;
-    const bool a_vec = ((uintptr_t)Asrc & 15u) == 0;
+    const bool a_vec = ((uintptr_t)Asrc & 3u) == 0;     // always, for fp32 data: 4-byte-aligned 16-byte loads
     for (int id = threadIdx.x; id < T.cols; id += 256) {      // 8 rows x cols / 8 octets; 8 consecutive lanes = one full 128-B line per plane
         const int r = id & 7, o = id >> 3;
         const float* src = Asrc + c.start + (long)r * T.cols + o * 8;
         f32x4 lo, hi;
         if (a_vec) {
-            lo = *(const gf32x4*)src;
-            hi = *(const gf32x4*)(src + 4);
+            const f32x4_a4 l4 = *(const gf32x4_a4*)src, h4 = *(const gf32x4_a4*)(src + 4);
+            lo = f32x4{l4[0], l4[1], l4[2], l4[3]};
+            hi = f32x4{h4[0], h4[1], h4[2], h4[3]};
         } else {
             const gfloat* g = as_global(src);
 #pragma unroll

@@ -308,7 +308,8 @@ def test_g3_covariance_vs_golden(N, dev, golden_dir):
                                             (256, (1, 1), (1, 1), (0, 0), (13, 21), 1),
                                             (64, (3, 3), (1, 1), (1, 1), (25, 42), 2),      # D = 576 = 4.5 x 128: padded rows + a 128-row remainder tile
                                             (512, (1, 1), (1, 1), (0, 0), (13, 21), 1),     # D = 512, L = 273 (padded to 288)
-                                            (128, (3, 3), (2, 2), (1, 1), (50, 84), 1)])    # D = 1152, stride 2
+                                            (128, (3, 3), (2, 2), (1, 1), (50, 84), 1),     # D = 1152, stride 2
+                                            (192, (3, 1), (1, 2), (0, 1), (20, 30), 3)])    # D = 576, non-square kernel / stride / padding, batch 3
 @pytest.mark.parametrize("mode", [0, 2, 3])
 def test_covariance_vs_oracle_mid_sizes(N, dev, cin, k, s, p, hw, B, mode):
     """All matrix-core paths of the SYRK: 0 = fp32 MFMA; 2 = two-term fp16 split forced (layers with D >= 512 take its second
