@@ -348,8 +348,10 @@ def end_to_end_training(N, dev, world, local_rank, basis_cache, steps, warmup, a
     batches = [synthetic_batch(batch_size, (15, 20), dev, seed=100 * local_rank + i) for i in range(4)]
     net = model
     if world > 1:
+        # find_unused_parameters=True is the reference's own setting (_base_/brnsrunetime.py:27); the frozen heads of future tasks
+        # and the teacher never receive gradients
         net = torch.nn.parallel.DistributedDataParallel(model, device_ids=[local_rank], broadcast_buffers=False,
-                                                        gradient_as_bucket_view=True)
+                                                        gradient_as_bucket_view=True, find_unused_parameters=True)
     fwd_bwd, opt_ms = [], []
 
     def one_step(i):
