@@ -321,7 +321,8 @@ def test_covariance_vs_oracle_mid_sizes(N, dev, cin, k, s, p, hw, B, mode):
     prev = ops.cov_set_split_mfma(mode)
     try:
         cov = ops.cov_accumulate_conv2d(x.to(dev), k, s, p)
-        assert _rel(cov, ref) <= REL
+        assert _rel(cov, ref) <= REL and _row_rel(cov, ref) <= REL
+        assert torch.equal(cov, ops.cov_accumulate_conv2d(x.to(dev), k, s, p))     # no float atomics: bitwise repeatable
         cov = ops.cov_accumulate_conv2d(x.to(dev), k, s, p, cov)  # second batch accumulates
         assert _rel(cov, ref + ref) <= REL
         assert torch.equal(cov, cov.t().contiguous())
