@@ -35,15 +35,18 @@ def assign_max_iou(priors: torch.Tensor, gt_bboxes: torch.Tensor, pos_iou_thr: f
 
 
 def random_sample(assigned: torch.Tensor, num: int, pos_fraction: float):
-    """RandomSampler (neg_pos_ub = -1) -> (pos_inds, neg_inds)."""
+    """RandomSampler (neg_pos_ub = -1) -> (pos_inds, neg_inds), both ascending.  Same draws as mmdet's
+    (task_modules/samplers/random_sampler.py:66-68, base_sampler.py:112-127): the permutation comes from the CPU default generator
+    whatever device the boxes live on, and the chosen indices are sorted afterwards (``.unique()``), so a seeded run picks the same
+    RoIs -- and hands ``select_five_rois`` the same row order -- as the reference."""
     pos = torch.nonzero(assigned > 0).flatten()
     neg = torch.nonzero(assigned == 0).flatten()
-    n_pos = min(int(num * pos_fraction), pos.numel())
+    n_pos = int(num * pos_fraction)
     if pos.numel() > n_pos:
-        pos = pos[torch.randperm(pos.numel(), device=pos.device)[:n_pos]]
-    n_neg = min(num - n_pos, neg.numel())
+        pos = pos[torch.randperm(pos.numel())[:n_pos].to(pos.device)].sort().values
+    n_neg = num - pos.numel()
     if neg.numel() > n_neg:
-        neg = neg[torch.randperm(neg.numel(), device=neg.device)[:n_neg]]
+        neg = neg[torch.randperm(neg.numel())[:n_neg].to(neg.device)].sort().values
     return pos, neg
 
 

@@ -306,3 +306,54 @@ def g7_coco():
 
 G7_COCO_CLASSES = ("person", "bicycle", "car", "motorcycle", "airplane", "bus", "train", "truck", "boat", "traffic light")
 G7_COCO_SPLITS = [([0, 5, 10], 1), ([0, 5, 10], 2), ([0, 4, 8, 10], 3)]
+
+
+# ---------------------------------------------------------------- G8: RoI dump (get_bbox_stuff, head:106-202)
+G8_NUM_CLASSES = 20
+G8_CANVAS = (800, 1344)                 # H, W of the padded input
+G8_FEAT_C = 4                           # channels of the stand-in RoI extractor (mmcv's RoIAlign is absent)
+# (name, torch seed, per image: (number of gts, number of jittered copies per gt, number of random proposals))
+G8_CASES = (
+    ("many_fg", 11, ((3, 12, 500), (4, 9, 480))),        # > 5 foreground rows: random foreground rows are dropped
+    ("few_fg", 12, ((1, 0, 300), (0, 0, 250))),          # 1 foreground row (the gt itself) + an image without gts: padded with background
+    ("pos_overflow", 13, ((5, 70, 700), (2, 10, 400))),  # > 128 positives in image 0: the sampler's random_choice on positives runs too
+)
+
+
+def g8_case(ci):
+    """-> per image dict(gt_bboxes [G x 4], gt_labels [G], proposals [N x 4], scores [N]); all fp32 / int64."""
+    name, seed, imgs = G8_CASES[ci]
+    rng = np.random.default_rng(8000 + seed)
+    H, W = G8_CANVAS
+    out = []
+    for (g, jit, nrand) in imgs:
+        cx, cy = rng.uniform(100, W - 100, g), rng.uniform(100, H - 100, g)
+        bw, bh = rng.uniform(40, 400, g), rng.uniform(40, 300, g)
+        gt = np.stack([np.clip(cx - bw / 2, 0, W), np.clip(cy - bh / 2, 0, H), np.clip(cx + bw / 2, 0, W), np.clip(cy + bh / 2, 0, H)], 1)
+        props = []
+        for b in gt:
+            w_, h_ = b[2] - b[0], b[3] - b[1]
+            s = rng.uniform(0.02, 0.45, (jit, 1))                # small to large jitter: IoUs on both sides of 0.5
+            d = rng.normal(0, 1, (jit, 4)) * s * np.array([w_, h_, w_, h_])
+            props.append(b[None] + d)
+        x1, y1 = rng.uniform(0, W - 20, nrand), rng.uniform(0, H - 20, nrand)
+        props.append(np.stack([x1, y1, np.minimum(x1 + rng.uniform(8, 500, nrand), W), np.minimum(y1 + rng.uniform(8, 400, nrand), H)], 1))
+        p = np.concatenate(props, 0) if props else np.zeros((0, 4))
+        p = np.stack([np.clip(np.minimum(p[:, 0], p[:, 2]), 0, W), np.clip(np.minimum(p[:, 1], p[:, 3]), 0, H),
+                      np.clip(np.maximum(p[:, 0], p[:, 2]), 0, W), np.clip(np.maximum(p[:, 1], p[:, 3]), 0, H)], 1)
+        p = p[rng.permutation(p.shape[0])]
+        out.append(dict(gt_bboxes=gt.astype(np.float32).reshape(-1, 4), gt_labels=rng.integers(0, G8_NUM_CLASSES, g).astype(np.int64),
+                        proposals=p.astype(np.float32), scores=rng.uniform(0, 1, p.shape[0]).astype(np.float32)))
+    return out
+
+
+def g8_extract(rois, channels=G8_FEAT_C, out=7):
+    """Stand-in for the RoI extractor (``bbox_roi_extractor(x, rois)``): a closed-form fp32 feature of the RoI's own
+    coordinates, so that a row of the dumped features identifies the RoI it came from.  torch in, torch out."""
+    import torch
+    g = torch.arange(out, dtype=torch.float32, device=rois.device)
+    c = torch.arange(1, channels + 1, dtype=torch.float32, device=rois.device)
+    base = rois[:, 1:5] * rois.new_tensor([1 / 1344.0, 1 / 800.0, 1 / 1344.0, 1 / 800.0])       # [R x 4] in [0, 1]
+    f = (base[:, 0, None, None, None] * c[None, :, None, None] + base[:, 1, None, None, None] * g[None, None, :, None] * 0.125
+         + base[:, 2, None, None, None] * g[None, None, None, :] * 0.0625 + base[:, 3, None, None, None] + rois[:, 0, None, None, None])
+    return f.contiguous()

@@ -321,10 +321,132 @@ def run_task_split():
     print(f"g7_task_split.json: {os.path.getsize(path) / 1024:.1f} KiB")
 
 
+# ---------------------------------------------------------------- G8 RoI dump (get_bbox_stuff)
+def _load_stock_roi_parts():
+    """The stock half of ``get_bbox_stuff`` is mmdet code the fork vendors: MaxIoUAssigner, RandomSampler, DeltaXYWHBBoxCoder,
+    ``BBoxHead.get_targets``, ``bbox2roi``, ``unpack_gt_instances``.  Load those files for real (in dependency order) and hang them
+    on the stand-in packages, so the reference's own ``get_bbox_stuff`` runs its own assign / sample / target code."""
+    import importlib
+    import re
+
+    def expose(pkg, **names):
+        m = importlib.import_module(pkg)
+        for k, v in names.items():
+            setattr(m, k, v)
+
+    expose("mmengine.utils", digit_version=lambda v: tuple(int(x) for x in re.findall(r"\d+", v)[:3]))
+    expose("mmdet.utils", util_mixins=R.load("mmdet/utils/util_mixins.py"), util_random=R.load("mmdet/utils/util_random.py"))
+    overlaps = R.load("mmdet/structures/bbox/bbox_overlaps.py")
+    expose("mmdet.structures.bbox", bbox_overlaps=overlaps.bbox_overlaps, get_box_tensor=lambda b: b,
+           cat_boxes=lambda boxes, dim=0: torch.cat(boxes, dim=dim))
+    ar = R.load("mmdet/models/task_modules/assigners/assign_result.py")
+    R.load("mmdet/models/task_modules/assigners/base_assigner.py")
+    iou = R.load("mmdet/models/task_modules/assigners/iou2d_calculator.py")
+    assigner = R.load("mmdet/models/task_modules/assigners/max_iou_assigner.py")
+    expose("mmdet.models.task_modules.assigners", AssignResult=ar.AssignResult)
+    sr = R.load("mmdet/models/task_modules/samplers/sampling_result.py")
+    R.load("mmdet/models/task_modules/samplers/base_sampler.py")
+    sampler = R.load("mmdet/models/task_modules/samplers/random_sampler.py")
+    expose("mmdet.models.task_modules.samplers", SamplingResult=sr.SamplingResult)
+    R.load("mmdet/models/task_modules/coders/base_bbox_coder.py")
+    coder = R.load("mmdet/models/task_modules/coders/delta_xywh_bbox_coder.py")
+    transforms = R.load("mmdet/structures/bbox/transforms.py")
+    misc = R.load("mmdet/models/utils/misc.py")
+    expose("mmdet.models.utils", multi_apply=misc.multi_apply, unpack_gt_instances=misc.unpack_gt_instances)
+    bbox_head = R.load("mmdet/models/roi_heads/bbox_heads/bbox_head.py")
+
+    class _Build:                       # TASK_UTILS.build(dict(type='BboxOverlaps2D')) inside MaxIoUAssigner.__init__
+        def register_module(self, *a, **k):
+            return lambda c: c
+
+        def build(self, cfg, *a, **k):
+            assert cfg["type"] == "BboxOverlaps2D"
+            return iou.BboxOverlaps2D()
+    assigner.TASK_UTILS = _Build()
+    # the fork's head file was loaded against the stand-ins: give it the real helpers it calls in get_bbox_stuff
+    ref_head.unpack_gt_instances = misc.unpack_gt_instances
+    ref_head.bbox2roi = transforms.bbox2roi
+    return assigner.MaxIoUAssigner, sampler.RandomSampler, coder.DeltaXYWHBBoxCoder, bbox_head.BBoxHead
+
+
+class _Bag:
+    """Attribute bag standing in for mmengine's InstanceData / DetDataSample (absent here)."""
+
+    def __init__(self, **kw):
+        self.__dict__.update(kw)
+
+    def pop(self, k):
+        return self.__dict__.pop(k)
+
+    def __contains__(self, k):
+        return k in self.__dict__
+
+    def __len__(self):
+        return int(next(iter(self.__dict__.values())).shape[0])
+
+
+def run_roi_dump():
+    from types import SimpleNamespace
+    MaxIoUAssigner, RandomSampler, Coder, BBoxHead = _load_stock_roi_parts()
+    out = {}
+    for ci, (case, seed, _) in enumerate(I.G8_CASES):
+        imgs = I.g8_case(ci)
+        # rcnn train_cfg of _base_/models/faster-rcnn_r50_fpn.py:86-101
+        assigner = MaxIoUAssigner(pos_iou_thr=0.5, neg_iou_thr=0.5, min_pos_iou=0.5, match_low_quality=False, ignore_iof_thr=-1)
+        sampler = RandomSampler(num=512, pos_fraction=0.25, neg_pos_ub=-1, add_gt_as_proposals=True)
+        seen = []
+        real_assign, real_sample = assigner.assign, sampler.sample
+
+        def assign(pred, gt, ign=None):
+            res = real_assign(pred, gt, ign)
+            seen.append(dict(gt_inds=res.gt_inds.clone()))
+            return res
+
+        def sample(res, pred, gt, **kw):
+            s = real_sample(res, pred, gt, **kw)
+            seen[-1].update(pos_inds=s.pos_inds.clone(), neg_inds=s.neg_inds.clone())
+            return s
+        assigner.assign, sampler.sample = assign, sample
+        head = SimpleNamespace(num_classes=I.G8_NUM_CLASSES, reg_decoded_bbox=False, bbox_coder=Coder(target_stds=[0.1, 0.1, 0.2, 0.2]))
+        head._get_targets_single = lambda *a, **k: BBoxHead._get_targets_single(head, *a, **k)
+        head.get_targets = lambda *a, **k: BBoxHead.get_targets(head, *a, **k)
+        head.get_roi_targets = lambda sampling_results, rcnn_train_cfg: list(head.get_targets(sampling_results, rcnn_train_cfg))  # bbox_task:449-454
+        head.get_mid_features = lambda f: f.flatten(1)                                          # bbox_task:290-323 without shared convs
+        extractor = lambda x, rois: I.g8_extract(rois)
+        extractor.num_inputs = 4
+        self_ = SimpleNamespace(bbox_assigner=assigner, bbox_sampler=sampler, bbox_roi_extractor=extractor, bbox_head=head,
+                                with_shared_head=False, train_cfg=SimpleNamespace(pos_weight=-1), counter=defaultdict(int))
+        rpn = [_Bag(bboxes=torch.from_numpy(im["proposals"]), scores=torch.from_numpy(im["scores"])) for im in imgs]
+        samples = [_Bag(metainfo={}, gt_instances=_Bag(bboxes=torch.from_numpy(im["gt_bboxes"]), labels=torch.from_numpy(im["gt_labels"])))
+                   for im in imgs]
+        x = [torch.zeros(len(imgs), 1, 1, 1)] * 4
+        torch.manual_seed(seed)
+        feats, cls_t, cls_w, box_t, box_w, rois = ref_head.StandardRoIReplayHead.get_bbox_stuff(self_, x, rpn, samples)
+        assert feats.shape[0] == 5, feats.shape
+        for i, s in enumerate(seen):
+            for k, v in s.items():
+                out[f"{case}__img{i}__{k}"] = v.numpy()
+        for k, v in dict(feats=feats, cls_t=cls_t, cls_w=cls_w, box_t=box_t, box_w=box_w, rois=rois).items():
+            out[f"{case}__{k}"] = v.numpy()
+        print(f"  {case}: fg rows kept {(cls_t != I.G8_NUM_CLASSES).sum().item()}, positives per image "
+              f"{[int(s['pos_inds'].numel()) for s in seen]}, negatives {[int(s['neg_inds'].numel()) for s in seen]}")
+    # the RPN-side use of the same assigner (faster-rcnn_r50_fpn.py:56-63: 0.7 / 0.3 / 0.3, low-quality matches on)
+    rpn_assigner = MaxIoUAssigner(pos_iou_thr=0.7, neg_iou_thr=0.3, min_pos_iou=0.3, match_low_quality=True, ignore_iof_thr=-1)
+    for ci, (case, _, _) in enumerate(I.G8_CASES):
+        for i, im in enumerate(I.g8_case(ci)):
+            res = rpn_assigner.assign(_Bag(priors=torch.from_numpy(im["proposals"])),
+                                      _Bag(bboxes=torch.from_numpy(im["gt_bboxes"]), labels=torch.from_numpy(im["gt_labels"])), None)
+            out[f"{case}__img{i}__rpn_gt_inds"] = res.gt_inds.numpy()
+    save("g8_roi_dump.npz", **out)
+
+
 if __name__ == "__main__":
     if sys.argv[1:] == ["g1b"]:        # only the 128-aligned optimizer fixtures
         for kind in I.G1B_KINDS:
             run_optimizer_aligned(kind)
+        sys.exit(0)
+    if sys.argv[1:] == ["g8"]:         # only the RoI-dump fixture
+        run_roi_dump()
         sys.exit(0)
     for kind in ("sgd", "sgd_nesterov", "adamw", "adamw_amsgrad", "adam", "sgdna"):
         run_optimizer(kind)
@@ -336,3 +458,4 @@ if __name__ == "__main__":
     run_replay_loss()
     run_ewc()
     run_task_split()
+    run_roi_dump()

@@ -342,3 +342,10 @@ def test_fused_double_softmax_ce_vs_torch_and_golden(N, dev, golden_dir):
     _, labels = I.g5_bank()
     out = ops.double_softmax_cross_entropy(kept.to(dev), torch.from_numpy(labels).to(dev))
     np.testing.assert_allclose(out.item(), gold["loss"], rtol=1e-6)
+
+
+def test_roi_dump_vs_reference_golden_on_device(N, dev, golden_dir):
+    """a13 with the boxes on the GPU: same assignment, same seeded draws (the permutations come from the CPU generator as in
+    mmdet's RandomSampler), same five rows as the reference's ``get_bbox_stuff`` (G8)."""
+    from roi_dump_check import check_roi_dump
+    check_roi_dump(N, golden_dir, dev)

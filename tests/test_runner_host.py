@@ -374,3 +374,10 @@ def test_class_sharded_prototype_bank_gloo_world2(N):
         np.testing.assert_array_equal(l, labels.numpy())
         assert c == centres
         assert all(np.array_equal(x, y.numpy()) for ml, rl in zip(m, masks) for x, y in zip(ml, rl))
+
+
+def test_roi_dump_vs_reference_golden(N, golden_dir):
+    """a13, the whole of ``get_bbox_stuff`` (head:106-202) against the reference's own output (G8): assignment, the sampler's
+    seeded draws, RoI order, targets and the exactly-five selection."""
+    from roi_dump_check import check_roi_dump
+    check_roi_dump(N, golden_dir, "cpu")
