@@ -357,3 +357,35 @@ def g8_extract(rois, channels=G8_FEAT_C, out=7):
     f = (base[:, 0, None, None, None] * c[None, :, None, None] + base[:, 1, None, None, None] * g[None, None, :, None] * 0.125
          + base[:, 2, None, None, None] * g[None, None, None, :] * 0.0625 + base[:, 3, None, None, None] + rois[:, 0, None, None, None])
     return f.contiguous()
+
+
+# ---------------------------------------------------------------- G9: teacher pseudo-labelling (det:65-109)
+G9_THRESHOLDS = ((0.5, 0.7), (0.5, 0.5), (0.3, 0.9))     # (rpn_thresh, roi_thresh): detector defaults (det:39-40), runner default (runner:356), a wide pair
+
+
+def g9_batch(seed=9):
+    """Two images: ground truth + what the teacher 'predicted' (boxes in score order as ``predict`` returns them, scores, old-class labels).
+    Built so that every branch of the loop is taken: predictions that sit on a gt (IoU > 0.7: skipped), near-duplicates of an earlier
+    prediction (skipped only if the earlier one was appended to the RoI set -- the set grows inside the loop), scores on both sides of
+    both thresholds; the second image has no ground truth at all."""
+    rng = np.random.default_rng(9000 + seed)
+    H, W = G8_CANVAS
+    out = []
+    for g, n_free in ((3, 14), (0, 9)):
+        cx, cy = rng.uniform(150, W - 150, g), rng.uniform(150, H - 150, g)
+        bw, bh = rng.uniform(60, 300, g), rng.uniform(60, 300, g)
+        gt = np.stack([cx - bw / 2, cy - bh / 2, cx + bw / 2, cy + bh / 2], 1).reshape(-1, 4)
+        preds = [b + rng.normal(0, 2.0, 4) for b in gt]                                   # on a gt
+        preds += [b + np.array([0.3, 0.2, -0.1, 0.1]) * (b[2] - b[0]) for b in gt]        # beside a gt (IoU around 0.5-0.6)
+        x1, y1 = rng.uniform(0, W - 200, n_free), rng.uniform(0, H - 200, n_free)
+        free = np.stack([x1, y1, x1 + rng.uniform(40, 190, n_free), y1 + rng.uniform(40, 190, n_free)], 1)
+        preds += list(free)
+        preds += [b + rng.normal(0, 1.5, 4) for b in free[: n_free // 2]]                 # near-duplicates of earlier predictions
+        p = np.stack(preds).astype(np.float32)
+        s = rng.uniform(0.05, 1.0, p.shape[0]).astype(np.float32)
+        nd = n_free // 2
+        s[-nd:] = s[-nd - n_free:-n_free][:nd] * np.float32(0.97)        # a duplicate scores just below its original: same side of most thresholds
+        order = np.argsort(-s, kind="stable")
+        out.append(dict(gt_bboxes=gt.astype(np.float32), gt_labels=rng.integers(15, 20, g).astype(np.int64),
+                        pred_bboxes=p[order], pred_scores=s[order], pred_labels=rng.integers(0, 15, p.shape[0]).astype(np.int64)))
+    return out

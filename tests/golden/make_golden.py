@@ -440,13 +440,66 @@ def run_roi_dump():
     save("g8_roi_dump.npz", **out)
 
 
+# ---------------------------------------------------------------- G9 teacher pseudo-labelling (det:65-109)
+def run_pseudo_labels():
+    """The reference's own ``FasterRCNNRoIReplay.loss`` with recording stand-ins for the teacher, the RPN head and the RoI head: what
+    is pinned is the fork's loop (which predictions join the RPN set / the RoI set, the growing RoI set, label zeroing for the RPN).
+    ``torchvision.ops.box_iou`` is absent from the image; the loop is given the reference tree's own ``bbox_overlaps``
+    (mmdet/structures/bbox/bbox_overlaps.py: the same intersection-over-union) in its place, so the IoU ARITHMETIC of torchvision
+    stays unpinned -- the inputs keep every IoU far from the 0.7 cut."""
+    import copy
+    import importlib
+    from types import SimpleNamespace
+    sys.path.insert(0, os.path.join(HERE, "..", ".."))
+    from nsgp_repre_amd.detection.structures import DetSample, Instances     # InstanceData / DetDataSample stand-ins (mmengine is absent)
+    overlaps = sys.modules.get("mmdet.structures.bbox.bbox_overlaps") or R.load("mmdet/structures/bbox/bbox_overlaps.py")
+    ref_det = R.load("mmdet/models/detectors/faster_rcnn_roi_replay.py")
+    ref_det.box_iou = lambda a, b: overlaps.bbox_overlaps(a, b)
+    out = {}
+    for ti, (rpn_t, roi_t) in enumerate(I.G9_THRESHOLDS):
+        imgs = I.g9_batch()
+        seen = {}
+
+        class Teacher:
+            def eval(self):
+                return self
+
+            def predict(self, inputs, samples, rescale=False):
+                for s, im in zip(samples, imgs):
+                    s.pred_instances = Instances(bboxes=torch.from_numpy(im["pred_bboxes"]), scores=torch.from_numpy(im["pred_scores"]),
+                                                 labels=torch.from_numpy(im["pred_labels"]))
+                return samples
+
+        def loss_and_predict(x, rpn_samples, proposal_cfg=None):
+            seen["rpn"] = [(s.gt_instances.bboxes.clone(), s.gt_instances.labels.clone()) for s in rpn_samples]
+            return {}, [None] * len(rpn_samples)
+
+        def roi_loss(x, rpn_results, samples):
+            seen["roi"] = [(s.gt_instances.bboxes.clone(), s.gt_instances.labels.clone()) for s in samples]
+            return {}
+        self_ = SimpleNamespace(extract_feat=lambda b: None, teacher_model=Teacher(), rpn_thresh=rpn_t, roi_thresh=roi_t, with_rpn=True,
+                                train_cfg=dict(rpn_proposal=None), test_cfg=SimpleNamespace(rpn=None),
+                                rpn_head=SimpleNamespace(loss_and_predict=loss_and_predict), roi_head=SimpleNamespace(loss=roi_loss))
+        samples = [DetSample(Instances(bboxes=torch.from_numpy(im["gt_bboxes"]), labels=torch.from_numpy(im["gt_labels"])), img_shape=I.G8_CANVAS)
+                   for im in imgs]
+        ref_det.FasterRCNNRoIReplay.loss(self_, torch.zeros(len(imgs), 3, 8, 8), samples)
+        for which in ("rpn", "roi"):
+            for i, (b, l) in enumerate(seen[which]):
+                out[f"t{ti}__{which}__img{i}__bboxes"] = b.numpy()
+                out[f"t{ti}__{which}__img{i}__labels"] = l.numpy()
+        print(f"  thresholds {rpn_t}/{roi_t}: RPN set sizes {[len(b) for b, _ in seen['rpn']]}, RoI set sizes {[len(b) for b, _ in seen['roi']]} "
+              f"from gts {[len(im['gt_bboxes']) for im in imgs]} + predictions {[len(im['pred_bboxes']) for im in imgs]}")
+    save("g9_pseudo_labels.npz", **out)
+
+
 if __name__ == "__main__":
     if sys.argv[1:] == ["g1b"]:        # only the 128-aligned optimizer fixtures
         for kind in I.G1B_KINDS:
             run_optimizer_aligned(kind)
         sys.exit(0)
-    if sys.argv[1:] == ["g8"]:         # only the RoI-dump fixture
+    if sys.argv[1:] == ["g8"]:         # only the RoI-dump and pseudo-label fixtures
         run_roi_dump()
+        run_pseudo_labels()
         sys.exit(0)
     for kind in ("sgd", "sgd_nesterov", "adamw", "adamw_amsgrad", "adam", "sgdna"):
         run_optimizer(kind)
@@ -459,3 +512,4 @@ if __name__ == "__main__":
     run_ewc()
     run_task_split()
     run_roi_dump()
+    run_pseudo_labels()

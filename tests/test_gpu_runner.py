@@ -349,3 +349,43 @@ def test_roi_dump_vs_reference_golden_on_device(N, dev, golden_dir):
     mmdet's RandomSampler), same five rows as the reference's ``get_bbox_stuff`` (G8)."""
     from roi_dump_check import check_roi_dump
     check_roi_dump(N, golden_dir, dev)
+
+
+def test_pseudo_labelled_sets_vs_reference_golden(N, dev, golden_dir):
+    """8f-2 through the detector: ``FasterRCNNRoIReplay.loss`` (fused sequential filter kernel) hands its RPN head and its RoI
+    head exactly the ground-truth sets the reference's own ``loss`` handed its heads on the same teacher output (G9), for three
+    threshold pairs.  The IoU arithmetic of the absent torchvision is not pinned by this (the reference was given its own tree's
+    bbox_overlaps); the loop -- growth of the RoI set, both thresholds, label zeroing for the RPN -- is."""
+    from types import SimpleNamespace
+    from nsgp_repre_amd.detection.structures import DetSample, Instances
+    from nsgp_repre_amd.detectors.faster_rcnn_roi_replay import FasterRCNNRoIReplay
+    G = np.load(f"{golden_dir}/g9_pseudo_labels.npz")
+    for ti, (rpn_t, roi_t) in enumerate(I.G9_THRESHOLDS):
+        imgs, seen = I.g9_batch(), {}
+
+        class Teacher(torch.nn.Module):
+            def predict(self, inputs, samples, rescale=False):
+                for s, im in zip(samples, imgs):
+                    s.pred_instances = Instances(bboxes=torch.from_numpy(im["pred_bboxes"]).to(dev), scores=torch.from_numpy(im["pred_scores"]).to(dev),
+                                                 labels=torch.from_numpy(im["pred_labels"]).to(dev))
+                return samples
+
+        class Rpn(torch.nn.Module):
+            def loss_and_predict(self, x, samples, proposal_cfg=None):
+                seen["rpn"] = [(s.gt_instances.bboxes.cpu().numpy(), s.gt_instances.labels.cpu().numpy()) for s in samples]
+                return {}, [None] * len(samples)
+
+        class Roi(torch.nn.Module):
+            def loss(self, x, rpn_results, samples):
+                seen["roi"] = [(s.gt_instances.bboxes.cpu().numpy(), s.gt_instances.labels.cpu().numpy()) for s in samples]
+                return {}
+        det = FasterRCNNRoIReplay(backbone=torch.nn.Identity(), neck=torch.nn.Identity(), rpn_head=Rpn(), roi_head=Roi())
+        det.teacher_model = Teacher()
+        det.rpn_thresh, det.roi_thresh = rpn_t, roi_t
+        samples = [DetSample(Instances(bboxes=torch.from_numpy(im["gt_bboxes"]).to(dev), labels=torch.from_numpy(im["gt_labels"]).to(dev)),
+                             img_shape=I.G8_CANVAS) for im in imgs]
+        det.loss(torch.zeros(len(imgs), 3, 8, 8, device=dev), samples)
+        for which in ("rpn", "roi"):
+            for i, (b, l) in enumerate(seen[which]):
+                assert np.array_equal(b, G[f"t{ti}__{which}__img{i}__bboxes"]), (ti, which, i)
+                assert np.array_equal(l, G[f"t{ti}__{which}__img{i}__labels"]), (ti, which, i)

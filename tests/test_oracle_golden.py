@@ -232,3 +232,35 @@ def test_g6_ewc_regulariser(golden_dir):
     loss.backward()
     for k in range(int(g["n_reg"])):
         np.testing.assert_allclose(params[str(g[f"name_{k}"])].grad.numpy(), g[f"grad_{k}"], rtol=1e-5, atol=1e-7)
+
+
+def _g9_sets(filter_fn, rpn_t, roi_t):
+    """gt sets the RPN / the RoI head train on after det:65-109, from a (boxes, scores, gt) -> (to_rpn, to_roi) filter."""
+    rpn, roi = [], []
+    for im in I.g9_batch():
+        b, s, g = torch.from_numpy(im["pred_bboxes"]), torch.from_numpy(im["pred_scores"]), torch.from_numpy(im["gt_bboxes"])
+        to_rpn, to_roi = filter_fn(b, s, g, rpn_t, roi_t)
+        lab, gl = torch.from_numpy(im["pred_labels"]), torch.from_numpy(im["gt_labels"])
+        rpn.append((torch.cat([g, b[to_rpn]]).numpy(), np.zeros(len(g) + int(to_rpn.sum()), np.int64)))     # RPN labels are zeroed (det:117-119)
+        roi.append((torch.cat([g, b[to_roi]]).numpy(), torch.cat([gl, lab[to_roi]]).numpy()))
+    return dict(rpn=rpn, roi=roi)
+
+
+def test_g9_pseudo_label_loop(golden_dir):
+    """8f-2: the oracle's restatement of the teacher pseudo-label loop against what the reference's own ``loss`` handed its RPN and
+    RoI heads (G9; IoU supplied by the reference tree's bbox_overlaps because torchvision is absent -- the IoU arithmetic itself
+    stays unpinned).  Also shows the fixture needs the growing RoI set: a filter that tests against the ORIGINAL gts only differs."""
+    G = np.load(os.path.join(golden_dir, "g9_pseudo_labels.npz"))
+
+    def no_growth(b, s, g, rpn_t, roi_t):
+        ok = (O.box_iou(b, g).max(dim=1).values <= 0.7) if len(g) else torch.ones(len(b), dtype=torch.bool)
+        return ok & (s > rpn_t), ok & (s > roi_t)
+    differs = False
+    for ti, (rpn_t, roi_t) in enumerate(I.G9_THRESHOLDS):
+        ours, naive = _g9_sets(O.pseudo_label_filter, rpn_t, roi_t), _g9_sets(no_growth, rpn_t, roi_t)
+        for which in ("rpn", "roi"):
+            for i, (b, l) in enumerate(ours[which]):
+                assert np.array_equal(b, G[f"t{ti}__{which}__img{i}__bboxes"]), (ti, which, i)
+                assert np.array_equal(l, G[f"t{ti}__{which}__img{i}__labels"]), (ti, which, i)
+                differs |= naive[which][i][0].shape != b.shape
+    assert differs
