@@ -24,7 +24,8 @@
 // instead of 43.  LDS: three 48 KiB stages (144 of the CU's 160 KiB).  K-step t: each loader waits for ITS OWN pieces of
 // stage t (counted vmcnt that leaves step t+1's in flight), all twelve waves meet at ONE raw s_barrier (everybody's pieces of t
 // have landed AND every consumer is done reading stage t-1); the loaders issue the pieces of step t+2 into the stage t-1
-// used, the consumers do 16 ds_read_b128 + 24 MFMAs.  Prefetch distance two full steps (~2.4 us).
+// used, the consumers do 16 ds_read_b128 + 24 MFMAs.  Prefetch distance two full steps (~2.4 us).  The consumers' two k16 halves
+// are software-pipelined ACROSS the barrier (PIPE, see the loop): bit-identical results, +0..4 % (proj_v2_pipe_study.log).
 // MB = 2 serves the 128-row layers (and a trailing 128-row remainder): the same code with consumer waves 4-7 idle.
 //
 // Measured and not kept -- the variants live in tools/proj_v2_bench.hip, their logs in profiles/r02/proj_v2_*_study.log:
@@ -93,7 +94,7 @@ __device__ __forceinline__ unsigned long long v2_uniform(unsigned long long x) {
 //   loader l (0..3): planes 2l, 2l+1 (octet l, both terms) of every block slot -> 12 (8) pieces per step, counted vmcnt(12 / 8).
 constexpr int V2L_THREADS = 768;
 
-template <int MB>
+template <int MB, bool PIPE = true>
 __device__ __forceinline__ void gemm_tile_f16x2_v2l(const void* __restrict__ Asplit, int a_block0, const void* __restrict__ Bsplit,
                                                     int b_block0, int K, char* smem, f32x16 (&acc)[2][2], int step0 = 0, int nsteps = -1) {
     // K = the operands' full contraction length (it sets the block stride); the tile contracts k32 steps [step0, step0 + nsteps)
@@ -183,15 +184,85 @@ __device__ __forceinline__ void gemm_tile_f16x2_v2l(const void* __restrict__ Asp
         }
         __builtin_amdgcn_sched_group_barrier(0x008, 16, 0);
     };
-    int t = 0;
-    for (; t + 2 < nk; t += 3) {
-        v2_barrier(); compute(IC<0>{});
-        v2_barrier(); compute(IC<1>{});
-        v2_barrier(); compute(IC<2>{});
+    if constexpr (!PIPE) {
+        int t = 0;
+        for (; t + 2 < nk; t += 3) {
+            v2_barrier(); compute(IC<0>{});
+            v2_barrier(); compute(IC<1>{});
+            v2_barrier(); compute(IC<2>{});
+        }
+        if (t < nk) { v2_barrier(); compute(IC<0>{}); ++t; }
+        if (t < nk) { v2_barrier(); compute(IC<1>{}); ++t; }
+        v2_barrier();
+        return;
     }
-    if (t < nk) { v2_barrier(); compute(IC<0>{}); ++t; }
-    if (t < nk) { v2_barrier(); compute(IC<1>{}); ++t; }
+    // ---- PIPE: the k16 halves of a step are software-pipelined ACROSS the step barrier.  In the plain schedule above every
+    // consumer wave leaves the barrier, issues its first 8 fragment reads and stalls until they land -- all eight waves at once,
+    // 64 KiB through a 128 B/clk LDS, with both waves of every SIMD waiting together and the matrix pipe idle.  Here the second
+    // half's fragments of stage s-1 stay in registers over the barrier and their 12 MFMAs run while the first-half reads of
+    // stage s are in flight; the second-half reads of stage s then fly under the first half's MFMAs.  Same 16 fragment registers.
+    // The reads of a stage must have LANDED before the barrier that hands the stage back to the loaders: lgkmcnt(0) in front of it.
+    h16x8 f0a[2][2], f0b[2][2], f1a[2][2], f1b[2][2];      // [32-row block][term] of k16 half 0 / half 1
+    auto read_half = [&](auto st, auto ks_, h16x8 (&fa)[2][2], h16x8 (&fb)[2][2]) {
+        constexpr int ST = decltype(st)::value, ks = decltype(ks_)::value;
+#pragma unroll
+        for (int p = 0; p < 2; ++p)
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                fa[i][p] = *reinterpret_cast<lds_frag>(abase + ST * V2_STAGE + ks * (4 * V2_PLANE) + p * V2_PLANE + i * 512);
+                fb[i][p] = *reinterpret_cast<lds_frag>(bbase + ST * V2_STAGE + ks * (4 * V2_PLANE) + p * V2_PLANE + i * 512);
+            }
+    };
+    auto mfma_half = [&](const h16x8 (&fa)[2][2], const h16x8 (&fb)[2][2]) {
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < 2; ++ni) acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[mi][1], fb[ni][0], acc[mi][ni], 0, 0, 0);
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < 2; ++ni) acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[mi][0], fb[ni][1], acc[mi][ni], 0, 0, 0);
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < 2; ++ni) acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[mi][0], fb[ni][0], acc[mi][ni], 0, 0, 0);
+    };
+    auto pin_half = [&]() {      // 8 x (one LDS read, one MFMA), then the remaining 4 MFMAs
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        }
+        __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+    };
+    auto first = [&](auto st) {            // stage 0 of the range: nothing to overlap the first reads with
+        v2_barrier();
+        if (!active) return;
+        read_half(st, IC<0>{}, f0a, f0b);
+        read_half(st, IC<1>{}, f1a, f1b);
+        mfma_half(f0a, f0b);
+        __builtin_amdgcn_sched_group_barrier(0x100, 16, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, 12, 0);
+    };
+    auto steady = [&](auto st) {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // half 1 of the previous stage is in registers: its LDS may be refilled
+        v2_barrier();
+        if (!active) return;
+        read_half(st, IC<0>{}, f0a, f0b);
+        mfma_half(f1a, f1b);                                    // previous stage, half 1
+        pin_half();
+        read_half(st, IC<1>{}, f1a, f1b);
+        mfma_half(f0a, f0b);
+        pin_half();
+    };
+    first(IC<0>{});
+    int t = 1;
+    for (; t + 2 < nk; t += 3) { steady(IC<1>{}); steady(IC<2>{}); steady(IC<0>{}); }
+    if (t < nk) { steady(IC<1>{}); ++t; }
+    if (t < nk) { steady(IC<2>{}); ++t; }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     v2_barrier();
+    if (active) mfma_half(f1a, f1b);
 }
 
 // ---- operand preparation ------------------------------------------------------------------------------------------------

@@ -344,14 +344,14 @@ __global__ __launch_bounds__(V2S_THREADS, 2) void v2s_kernel(const void* As, con
 }
 
 // loader / consumer form: 768 threads
-template <int MB>
+template <int MB, bool PIPE = true>
 __global__ __launch_bounds__(V2L_THREADS, 3) void v2l_kernel(const void* As, const void* Bs, const float* rinv, const float* cinv,
                                                              float* C, int M, int N, int K) {
     extern __shared__ __attribute__((aligned(16))) char smem_c[];
     f32x16 acc[2][2];
     zero_acc(acc);
     const int m0 = blockIdx.y * (MB * 64), n0 = blockIdx.x * 128;
-    gemm_tile_f16x2_v2l<MB>(As, m0 / 64, Bs, n0 / 64, K, smem_c, acc);
+    gemm_tile_f16x2_v2l<MB, PIPE>(As, m0 / 64, Bs, n0 / 64, K, smem_c, acc);
     if ((int)(threadIdx.x >> 6) >= 2 * MB) return;
     float* smem = reinterpret_cast<float*>(smem_c);
     acc_to_lds(smem, acc);
@@ -521,6 +521,21 @@ static int run_shape(int M, int N, int K, bool wide_rows) {
         const double tl2 = fl / time_it([&] { hipLaunchKernelGGL(v2l_kernel<4>, dim3(N / 128, M / 256), dim3(V2L_THREADS), V2_SMEM_BYTES, 0, As, Bs, rinv, cinv, C, M, N, K); }) / 1e9;
         printf("  gen-2 256x128 loader/consumer (8 + 4 waves): %.1f TF-eq | all-waves-load right after: %.1f | loader/consumer again: %.1f | differing elements %zu (MB=2 form %zu) | unstable repeats %d\n",
                tl, tb, tl2, bad, bad2, unstable_l);
+        {   // the same tile without the cross-barrier software pipeline (PIPE = false): the round-2 first form
+            auto plain = v2l_kernel<4, false>;
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(plain), hipFuncAttributeMaxDynamicSharedMemorySize, V2_SMEM_BYTES);
+            CK(hipMemset(C, 0, (size_t)M * N * 4));
+            hipLaunchKernelGGL(plain, dim3(N / 128, M / 256), dim3(V2L_THREADS), V2_SMEM_BYTES, 0, As, Bs, rinv, cinv, C, M, N, K);
+            CK(hipGetLastError());
+            CK(hipMemcpy(cr.data(), C, cr.size() * 4, hipMemcpyDeviceToHost));
+            size_t badp = 0; for (size_t i = 0; i < cr.size(); ++i) badp += cr[i] != cl[i];
+            const double tp1 = fl / time_it([&] { hipLaunchKernelGGL(plain, dim3(N / 128, M / 256), dim3(V2L_THREADS), V2_SMEM_BYTES, 0, As, Bs, rinv, cinv, C, M, N, K); }) / 1e9;
+            const double tq1 = fl / time_it([&] { hipLaunchKernelGGL(v2l_kernel<4>, dim3(N / 128, M / 256), dim3(V2L_THREADS), V2_SMEM_BYTES, 0, As, Bs, rinv, cinv, C, M, N, K); }) / 1e9;
+            const double tp2 = fl / time_it([&] { hipLaunchKernelGGL(plain, dim3(N / 128, M / 256), dim3(V2L_THREADS), V2_SMEM_BYTES, 0, As, Bs, rinv, cinv, C, M, N, K); }) / 1e9;
+            const double tq2 = fl / time_it([&] { hipLaunchKernelGGL(v2l_kernel<4>, dim3(N / 128, M / 256), dim3(V2L_THREADS), V2_SMEM_BYTES, 0, As, Bs, rinv, cinv, C, M, N, K); }) / 1e9;
+            printf("  halves pipelined across the step barrier: %.1f / %.1f TF-eq | one step at a time (plain): %.1f / %.1f | elements differing between the two %zu\n",
+                   tq1, tq2, tp1, tp2, badp);
+        }
     }
     printf("  gen-2 128x128 (MB=2) tile             : %.3f ms = %6.1f TF fp32-equivalent | worst per-row rel err %.3g | max|MB4 - MB2| on the sampled rows %.3g\n", t2, fl / t2 / 1e9, worst3, M % 256 == 0 ? d23 : -1.0);
     printf("  operand preparation: row split of A %.3f ms (%.2f TB/s of read+write), column scales + split of P^T %.3f ms\n", t_rows, 2.0 * M * K * 4 / t_rows / 1e9, t_cols);
