@@ -41,7 +41,9 @@ const char* nsgp_last_error(void);
 int nsgp_device_count(void);
 int nsgp_device_arch(char* buf, int buflen);
 /* Test-run diagnostics (no reference counterpart): from now on a SIGABRT first writes the native call stack of the
- * aborting thread to fd 2, then runs the handler that was installed before (e.g. Python's faulthandler).  Idempotent. */
+ * aborting thread to fd 2, then runs the handler that was installed before (e.g. Python's faulthandler).  Idempotent.
+ * Environment: NSGP_DEBUG_ALLOC=1 makes nsgp_plan_create / nsgp_plan_destroy print the addresses of the plan's own device and
+ * pinned buffers to stderr (to place a faulting address reported by the runtime). */
 int nsgp_debug_install_abort_backtrace(void);
 
 /* ------------------------------------------------------------------------

@@ -18,6 +18,8 @@
 //           that share a P column panel land on the same XCD (blockIdx % 8).
 #include <algorithm>
 #include <cmath>
+#include <cstdio>
+#include <cstdlib>
 #include <new>
 #include <vector>
 
@@ -818,6 +820,11 @@ extern "C" int nsgp_plan_create(nsgp_plan_t** out, const nsgp_tensor_t* tensors,
         PLAN_HIP(hipEventCreateWithFlags(&P->ev[s], hipEventDisableTiming));
     }
 #undef PLAN_HIP
+    if (getenv("NSGP_DEBUG_ALLOC")) {    // diagnostics: where this plan's own buffers live (to place a faulting address)
+        fprintf(stderr, "[nsgp alloc] plan %p: tensors %p +%zu, chunks %p +%zu, layers %p, tiles %p, dyn_bytes %zu\n", (void*)P, P->d_tensors,
+                sizeof(TensorDev) * td.size(), P->d_chunks, sizeof(ChunkDev) * cd.size(), P->d_layers, P->d_tiles, P->dyn_bytes);
+        for (int s = 0; s < NSLOT; ++s) fprintf(stderr, "[nsgp alloc]   slot %d: pinned %p device %p\n", s, (void*)P->h_dyn[s], (void*)P->d_dyn[s]);
+    }
     int rc;
     if ((rc = enable_big_lds(nsgp_lowrank_p1_kernel<NSGP_OPT_SGD>)) || (rc = enable_big_lds(nsgp_lowrank_p1_kernel<NSGP_OPT_ADAM>)) ||
         (rc = enable_big_lds(nsgp_lowrank_p2_kernel<NSGP_OPT_SGD>)) || (rc = enable_big_lds(nsgp_lowrank_p2_kernel<NSGP_OPT_ADAM>)) ||
@@ -836,6 +843,7 @@ extern "C" int nsgp_plan_destroy(nsgp_plan_t* P) {
     if (!P) return NSGP_OK;
     // Every launch of this plan is followed by an event record on its stream (nsgp_plan_step): waiting for the used slots
     // means no kernel still reads the tables, and no copy still reads the pinned ring, when they are released below.
+    if (getenv("NSGP_DEBUG_ALLOC")) fprintf(stderr, "[nsgp alloc] destroy plan %p\n", (void*)P);
     hipError_t first = hipSuccess;
     const char* what = "";
     auto keep = [&](hipError_t e, const char* w) { if (e != hipSuccess && first == hipSuccess) { first = e; what = w; } };

@@ -30,6 +30,8 @@ __global__ __launch_bounds__(64) void repre_pseudo_label_kernel(const float4* __
                                                                 unsigned char* __restrict__ add_roi) {
     __shared__ float gtmax[PL_MAX_BOXES];
     __shared__ unsigned char in_roi[PL_MAX_BOXES];
+    __shared__ float4 sbox[PL_MAX_BOXES];          // boxes and scores staged once: the ordered walk below then touches LDS only
+    __shared__ float sscore[PL_MAX_BOXES];         // (a global load on every dependent step cost ~0.5 us per box)
     const int lane = threadIdx.x;
     for (int k = lane; k < P; k += 64) {
         float m = 0.0f;
@@ -37,16 +39,18 @@ __global__ __launch_bounds__(64) void repre_pseudo_label_kernel(const float4* __
         for (int g = 0; g < G; ++g) m = fmaxf(m, box_iou1(b, gt[g]));
         gtmax[k] = m;
         in_roi[k] = 0;
+        sbox[k] = b;
+        sscore[k] = scores[k];
     }
     __syncthreads();
     for (int k = 0; k < P; ++k) {
-        const float4 b = boxes[k];
+        const float4 b = sbox[k];
         float m = gtmax[k];
         for (int j = lane; j < k; j += 64)
-            if (in_roi[j]) m = fmaxf(m, box_iou1(b, boxes[j]));
+            if (in_roi[j]) m = fmaxf(m, box_iou1(b, sbox[j]));
         for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off, 64));
         const bool keep = !(m > iou_thr);          // `if max_iou > 0.7: continue`
-        const float s = scores[k];
+        const float s = sscore[k];
         const bool rp = keep && (s > rpn_thr), ro = keep && (s > roi_thr);
         if (lane == 0) {
             add_rpn[k] = rp;

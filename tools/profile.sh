@@ -9,6 +9,8 @@ export TMPDIR=/tmp
 B="python3 bench.py --steps 10 --warmup 2 --hot-path-only"
 echo "trace pass" >> gpurun_out/profile_progress.log
 timeout -k 10 170 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o trace -- $B > $OUT/trace.log 2>&1 || echo "trace failed" >> $OUT/trace.log
+echo "trace pass (training step)" >> gpurun_out/profile_progress.log
+timeout -k 10 240 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_e2e -o trace -- python3 bench.py --steps 10 --warmup 3 --no-extras > $OUT/trace_e2e.log 2>&1 || echo "trace_e2e failed" >> $OUT/trace_e2e.log
 echo "pmc pass" >> gpurun_out/profile_progress.log
 timeout -k 10 170 rocprofv3 --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F32 --output-format csv -d $OUT/pmc_sq -o pmc -- $B > $OUT/pmc_sq.log 2>&1 || echo "pmc_sq failed" >> $OUT/pmc_sq.log
 echo "pmc pass" >> gpurun_out/profile_progress.log

@@ -25,9 +25,13 @@ def short(name):
     return name[:80]
 
 
+def suffix(f):      # the trace of the default bench command (training step) is kept beside the hot-path-only one
+    return "_training_step" if "trace_e2e" in f else ""
+
+
 for f in glob.glob(os.path.join(src, "**", "*kernel_stats.csv"), recursive=True):
     rows = list(csv.reader(open(f)))
-    with open(os.path.join(dst, "kernel_stats_top.csv"), "w", newline="") as o:
+    with open(os.path.join(dst, f"kernel_stats_top{suffix(f)}.csv"), "w", newline="") as o:
         w = csv.writer(o)
         for r in rows[:26]:
             w.writerow([c[:120] for c in r])
@@ -39,7 +43,7 @@ for f in glob.glob(os.path.join(src, "**", "*kernel_trace.csv"), recursive=True)
         n = r.get("Kernel_Name", "")
         if any(k in n for k in OURS):
             dur[short(n)].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
-    with open(os.path.join(dst, "our_kernels_duration_us.csv"), "w", newline="") as o:
+    with open(os.path.join(dst, f"our_kernels_duration_us{suffix(f)}.csv"), "w", newline="") as o:
         w = csv.writer(o)
         w.writerow(["kernel", "calls", "avg_us", "min_us", "max_us"])
         for k, v in sorted(dur.items()):
