@@ -1,5 +1,5 @@
 import sys, time, torch
-sys.path.insert(0, '.')
+import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import nsgp_repre_amd as N
 dev = torch.device('cuda:0')
 g = torch.Generator().manual_seed(0)
