@@ -323,9 +323,10 @@ def end_to_end_training(N, dev, world, local_rank, basis_cache, steps, warmup, a
     step.  The detector is nsgp_repre_amd.detection (stock recipe in plain PyTorch-ROCm; mmdet is not in the image)."""
     import copy
     import torch.distributed as dist
-    from nsgp_repre_amd.detection import build_faster_rcnn, synthetic_batch
+    from nsgp_repre_amd.detection import build_faster_rcnn, relocate_segment_final_weights, synthetic_batch
     torch.manual_seed(4321)
     model = build_faster_rcnn(depth=50, num_classes=20, task_id=2, task_split=[0, 15, 20]).to(dev)
+    relocate_segment_final_weights(model)      # guard against a stock MIOpen over-read (profiles/README.md, incident analysis)
     head = model.roi_head
     head.replay, K = True, 150
     head.bbox_featss = torch.relu(torch.randn(K, 12544, device=dev))

@@ -18,8 +18,8 @@ from .boxes import AnchorGenerator, bbox2delta, box_iou, delta2bbox
 from .backbone import FPN, ResNet
 from .rpn_head import RPNHead
 from .roi_parts import RoIAlignExtractor, StandaloneRoIHead, assign_max_iou, random_sample
-from .build import build_faster_rcnn, synthetic_batch
+from .build import build_faster_rcnn, relocate_segment_final_weights, synthetic_batch
 
 __all__ = ["DetSample", "Instances", "AnchorGenerator", "bbox2delta", "box_iou", "delta2bbox", "FPN", "ResNet", "RPNHead",
            "RoIAlignExtractor", "StandaloneRoIHead", "assign_max_iou", "random_sample", "build_faster_rcnn",
-           "synthetic_batch"]
+           "synthetic_batch", "relocate_segment_final_weights"]

@@ -69,9 +69,10 @@ def _batches(dev, n, classes, seed, h=192, w=256):
 
 
 def test_detector_modes(N, dev):
-    from nsgp_repre_amd.detection import build_faster_rcnn
+    from nsgp_repre_amd.detection import build_faster_rcnn, relocate_segment_final_weights
     torch.manual_seed(0)
     model = build_faster_rcnn(width=16, fc_out_channels=64, task_id=1).to(dev).train()
+    relocate_segment_final_weights(model)
     x, samples = _batches(dev, 1, (0, 15), 0)[0]
     losses = model(x, copy.deepcopy(samples), mode="loss")
     assert set(losses) == {"loss_rpn_cls", "loss_rpn_bbox", "loss_cls", "loss_bbox", "acc"}
@@ -100,7 +101,7 @@ def test_two_task_cycle_on_the_detector(N, dev):
     pass under the hooks + RoI dump; task 2 on classes 15-19 with the teacher, the prototype bank from task 1's
     files and NSGP-projected steps.  Checks the hand-off files, the loss dict, and the defining property of NSGP
     on a real backbone layer: the weight change annihilates the old task's dominant input directions."""
-    from nsgp_repre_amd.detection import build_faster_rcnn
+    from nsgp_repre_amd.detection import build_faster_rcnn, relocate_segment_final_weights
     torch.manual_seed(3)
     split = [0, 15, 20]
     ignore = ["rpn", "roi_head"]
@@ -120,6 +121,7 @@ def test_two_task_cycle_on_the_detector(N, dev):
         w1, w2 = os.path.join(td, "run_1"), os.path.join(td, "run_2")
         os.makedirs(w1), os.makedirs(w2)
         m1 = build_faster_rcnn(width=16, fc_out_channels=64, task_id=1, task_split=split).to(dev)
+        relocate_segment_final_weights(m1)
         o1 = N.SGDNSCL(m1.parameters(), lr=0.002, momentum=0.9, weight_decay=1e-4, svd=True)
         r1 = N.runner.BRNullSpaceRunner(m1, o1, w1, task_id=1, train_task_split=split, ignore_keys=ignore)
         cov, rois = r1.train(step_fn, _batches(dev, 3, (0, 15), 1), cov_forward=cov_fwd, cov_batches=_batches(dev, 15, (0, 15), 2),
@@ -137,6 +139,7 @@ def test_two_task_cycle_on_the_detector(N, dev):
         assert os.path.exists(os.path.join(w1, "best_final.pth"))
 
         m2 = build_faster_rcnn(width=16, fc_out_channels=64, task_id=2, task_split=split, previous_path=w1).to(dev)
+        relocate_segment_final_weights(m2)
         m2.load_state_dict(m1.state_dict())
         assert m2.roi_head.replay and m2.roi_head.bbox_featss.shape[1] == 12544
         assert sorted(set(m2.roi_head.tmp_label.tolist())) == list(range(15))
@@ -177,3 +180,36 @@ def test_two_task_cycle_on_the_detector(N, dev):
         assert (dict(m2.named_parameters())["rpn_head.rpn_conv.weight"] - before["rpn_head.rpn_conv.weight"]).norm() > 0
         cov2 = torch.load(os.path.join(w2, "covariance.pth"), weights_only=True)
         assert len(cov2) == 61
+
+
+def test_segment_final_conv_weight_is_relocated(N, dev):
+    """The harness guard against the MIOpen over-read that aborted round 1 (profiles/README.md, incident analysis): rebuild the
+    dangerous layout on purpose -- a 512-byte 1x1 conv weight as the last block of a full 2 MiB segment with nothing mapped behind
+    it -- WITHOUT running MIOpen on it, let the guard move it, then run forward + backward (backward-data is the kernel that reads
+    past the weight) on the relocated weight."""
+    from nsgp_repre_amd.detection import relocate_segment_final_weights
+    fill, final = [], None
+    for _ in range(64 * 4096):
+        t = torch.empty(128, device=dev)                      # one 512-byte block
+        fill.append(t)
+        end = t.data_ptr() + 512
+        if end % (1 << 21):
+            continue
+        segs = [(s_["address"], s_["address"] + s_["total_size"]) for s_ in torch.cuda.memory_snapshot()]
+        if any(e == end for _, e in segs) and not any(a == end for a, _ in segs):
+            final = t
+            break
+    assert final is not None
+    conv = torch.nn.Conv2d(16, 8, 1).to(dev)
+    with torch.no_grad():
+        final.view(8, 16, 1, 1).copy_(conv.weight)
+    conv.weight.data = final.view(8, 16, 1, 1)                # the layout of the incident
+    del fill
+    end_before = conv.weight.data_ptr() + 512
+    assert relocate_segment_final_weights(conv) >= 1
+    assert conv.weight.data_ptr() + 512 != end_before and torch.equal(conv.weight.data.flatten(), final)
+    assert relocate_segment_final_weights(conv) == 0           # nothing left to move
+    x = torch.randn(2, 16, 8, 8, device=dev, requires_grad=True)
+    conv(x).square().mean().backward()
+    torch.cuda.synchronize()
+    assert torch.isfinite(x.grad).all() and torch.isfinite(conv.weight.grad).all()

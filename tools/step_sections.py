@@ -15,7 +15,7 @@ import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import nsgp_repre_amd as N  # noqa: E402
-from nsgp_repre_amd.detection import build_faster_rcnn, synthetic_batch  # noqa: E402
+from nsgp_repre_amd.detection import build_faster_rcnn, relocate_segment_final_weights, synthetic_batch  # noqa: E402
 
 
 def main():
@@ -26,6 +26,7 @@ def main():
     dev = torch.device("cuda", 0)
     torch.manual_seed(4321)
     model = build_faster_rcnn(depth=50, num_classes=20, task_id=2, task_split=[0, 15, 20]).to(dev)
+    relocate_segment_final_weights(model)      # guard against a stock MIOpen over-read (profiles/README.md, incident analysis)
     head = model.roi_head
     head.replay = True
     head.bbox_featss = torch.relu(torch.randn(150, 12544, device=dev))
