@@ -450,8 +450,47 @@ def run_pseudo_labels():
     import copy
     import importlib
     from types import SimpleNamespace
-    sys.path.insert(0, os.path.join(HERE, "..", ".."))
-    from nsgp_repre_amd.detection.structures import DetSample, Instances     # InstanceData / DetDataSample stand-ins (mmengine is absent)
+
+    class Instances:
+        """What the loop needs of mmengine's InstanceData (absent here), written out independently of the product's own stand-in:
+        equally long tensors; ``len``; iteration yields one-row instances; ``inst['field']``; ``__delattr__``; ``cat`` of a list."""
+
+        def __init__(self, **fields):
+            object.__setattr__(self, "_f", dict(fields))
+
+        def __getattr__(self, k):
+            f = object.__getattribute__(self, "_f")
+            if k in f:
+                return f[k]
+            raise AttributeError(k)
+
+        def __setattr__(self, k, v):
+            self._f[k] = v
+
+        def __delattr__(self, k):
+            del self._f[k]
+
+        def __getitem__(self, k):
+            return self._f[k] if isinstance(k, str) else Instances(**{n: v[k:k + 1] for n, v in self._f.items()})
+
+        def __len__(self):
+            return int(next(iter(self._f.values())).shape[0]) if self._f else 0
+
+        def __iter__(self):
+            return (self[i] for i in range(len(self)))
+
+        def __deepcopy__(self, memo):
+            return Instances(**{n: v.clone() for n, v in self._f.items()})
+
+        def cat(self, items):
+            return Instances(**{n: torch.cat([it._f[n] for it in items]) for n in items[0]._f})
+
+    class DetSample:
+        def __init__(self, gt_instances, img_shape=None):
+            self.gt_instances, self.img_shape, self.pred_instances = gt_instances, img_shape, None
+
+        def __deepcopy__(self, memo):
+            return DetSample(copy.deepcopy(self.gt_instances, memo), self.img_shape)
     overlaps = sys.modules.get("mmdet.structures.bbox.bbox_overlaps") or R.load("mmdet/structures/bbox/bbox_overlaps.py")
     ref_det = R.load("mmdet/models/detectors/faster_rcnn_roi_replay.py")
     ref_det.box_iou = lambda a, b: overlaps.bbox_overlaps(a, b)
