@@ -32,7 +32,7 @@ extern "C" {
 #define NSGP_ERR_WORKSPACE (-3) /* workspace too small */
 #define NSGP_ERR_LIMIT (-4)     /* a fixed capacity was exceeded (e.g. > NSGP_MAX_HYPER combos) */
 
-#define NSGP_ABI_VERSION 6
+#define NSGP_ABI_VERSION 7
 #define NSGP_MAX_HYPER 32 /* distinct hyper-parameter sets per plan step */
 
 int nsgp_abi_version(void);
@@ -77,12 +77,15 @@ typedef struct {
     int32_t rows;       /* Cout  = update.size(0)            (projected tensors only) */
     int32_t cols;       /* D     = numel / rows = Cin*kh*kw  (projected tensors only) */
     int32_t hyper;      /* index into the per-step hyper array */
-    int32_t rank;       /* low-rank form (optional): number of TOP eigenvectors r = first_col of the projector */
-    const float* basis; /* low-rank form (optional): V [cols x cols] row-major, eigenvectors in columns (descending);
-                           when non-NULL and 0 < 4*rank <= cols the step applies
-                           p += basis_scale * (u - (u U) U^T),  U = V[:, :rank]  ==  u @ (basis_scale * V_tail V_tail^T)
-                           in 4*Cout*D*r FLOP instead of 2*Cout*D^2; otherwise the dense `proj` is used */
-    float basis_scale;  /* 1/||P||_F for Frobenius-normalised projectors (SGD_NSCL.py:282-283), else 1 */
+    int32_t rank;       /* low-rank form (optional): number of REMOVED directions r (the top eigenvectors = first_col of the projector) */
+    const float* basis; /* low-rank form (optional, ABI 7): U as k-quads [cols/4][rpad][4] fp32, rpad = rank rounded up to 32,
+                           columns >= rank zero (element (k, j) at ((k/4)*rpad + j)*4 + k%4).  With `basis_rows` non-NULL,
+                           0 < rank <= 128, rows % 32 == 0 and cols % 32 == 0 the step applies
+                           p += basis_scale * (u - (u U) U^T)      (the north star's g - U (U^T g))
+                           in 4*Cout*D*r FLOP and no projector traffic instead of u @ proj.  The CALLER vouches that
+                           proj == basis_scale * (I - U U^T) as built by nsgp_build_projector_head from the same U;
+                           otherwise leave both NULL and the dense `proj` is used */
+    float basis_scale;  /* 1/||I - U U^T||_F for Frobenius-normalised projectors (SGD_NSCL.py:282-283), else 1 */
     int32_t split_kind; /* 0: no split copy; 1: proj_split holds the three-term bf16 split (nsgp_split_projector);
                            2: the pre-tiled, column-scaled two-term fp16 split (nsgp_split_projector_f16) */
     const void* proj_split; /* optional split copy of proj^T.  When every 128-aligned projected tensor of a plan carries one
@@ -94,6 +97,7 @@ typedef struct {
                            NULL = fp32 MFMA */
     float split_scale;  /* unused since ABI 6 (the fp16 split carries its per-column scales itself); keep 0 */
     int32_t reserved;
+    const float* basis_rows; /* low-rank form (ABI 7): the same U row-major [cols][rpad] fp32 */
 } nsgp_tensor_t;
 
 /* Per-step hyper-parameters of one param group (host values, fp64->fp32 as torch does). */
@@ -138,7 +142,8 @@ int nsgp_plan_step(nsgp_plan_t* plan, float* const* grads, const nsgp_hyper_t* h
 int nsgp_plan_stats(const nsgp_plan_t* plan, double* gemm_flops, double* algorithmic_bytes,
                     int* n_tiles, int* n_projected);
 
-/* Layers that take the low-rank form and their FLOPs (sum 4*Cout*D*r), tile counts of its two phases. */
+/* Layers that take the low-rank form and their FLOPs (sum 4*Cout*D*r); workgroups of its T = u U launch (one per 32-row
+ * block) and wave units of its apply launch (32 rows x <= 256 columns each, padded to a multiple of four). */
 int nsgp_plan_lowrank_stats(const nsgp_plan_t* plan, int* n_lowrank, double* lowrank_flops,
                             int* n_tiles_p1, int* n_tiles_p2);
 /* Kind of split the plan's dense projection launch uses: 0 = fp32 MFMA, 1 = three-term bf16, 2 = two-term fp16. */
@@ -207,6 +212,12 @@ int nsgp_cov_accumulate_linear(const float* x, int batch, int features, float* c
 size_t nsgp_projector_scratch_bytes(int D);
 int nsgp_build_projector(const float* V, int D, int first_col, int normalise, float* P,
                          void* scratch, size_t scratch_bytes, void* stream);
+/* The same projector from the other side (ABI 7): P = I - U U^T (/ ||P||_F if normalise) with U [D x rpad] row-major
+ * fp32 = the `first_col` REMOVED directions V[:, :first_col], orthonormal, zero-padded to rpad columns (rpad a multiple of
+ * 32, <= 128; D % 32 == 0).  For an orthonormal V this IS basis basis^T of SGD_NSCL.py:270-285; built this way P is exactly
+ * idempotent-complement in form, bit-symmetric, and the step may apply it as p += c (u - (u U) U^T) (nsgp_tensor_t.basis). */
+int nsgp_build_projector_head(const float* U, int D, int rpad, int normalise, float* P,
+                              void* scratch, size_t scratch_bytes, void* stream);
 
 /* ------------------------------------------------------------------------
  * Prototype selection kernels  (K6, K7)

@@ -15,7 +15,8 @@ class TensorDesc(C.Structure):
     _fields_ = [("param", C.c_void_p), ("state0", C.c_void_p), ("state1", C.c_void_p), ("state2", C.c_void_p),
                 ("proj", C.c_void_p), ("numel", C.c_int64), ("rows", C.c_int32), ("cols", C.c_int32),
                 ("hyper", C.c_int32), ("rank", C.c_int32), ("basis", C.c_void_p), ("basis_scale", C.c_float),
-                ("split_kind", C.c_int32), ("proj_split", C.c_void_p), ("split_scale", C.c_float), ("reserved", C.c_int32)]
+                ("split_kind", C.c_int32), ("proj_split", C.c_void_p), ("split_scale", C.c_float), ("reserved", C.c_int32),
+                ("basis_rows", C.c_void_p)]
 
 
 class Hyper(C.Structure):
@@ -49,6 +50,7 @@ SIGNATURES = {
     "nsgp_cov_accumulate_linear": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p]),
     "nsgp_projector_scratch_bytes": (C.c_size_t, [C.c_int]),
     "nsgp_build_projector": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "nsgp_build_projector_head": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
     "nsgp_ewc_loss": (C.c_int, [C.c_void_p, C.c_int, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p]),
     "nsgp_ewc_grad": (C.c_int, [C.c_void_p, C.c_int, C.c_float, C.c_void_p, C.c_void_p]),
     "repre_pseudo_label_filter": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_float, C.c_float, C.c_float,

@@ -56,11 +56,13 @@ struct LayerDev {
     int tensor;
     int rows, cols;
     int hyper;
-    // low-rank form (rank > 0): V, r, T = (scale*S) U  [rows x rpad], its split-K slabs, 1/||P||_F
-    const float* basis;
+    // low-rank form (rank > 0): U as k-quads [D/4][rpad][4] and row-major [D][rpad] (columns >= rank are zero),
+    // T = (scale*S) U  [rows x rpad], c = 1/||I - U U^T||_F (or 1)
+    const float* ukq;
+    const float* urm;
     float* T;
-    float* slabs;
-    int rank, rpad, nsplit, kchunk;
+    float* slabs;       // nsplit > 1: [nsplit][rows][rpad] partial T of each K range
+    int rank, rpad, nsplit;
     float basis_scale;
     const void* split;     // split copy of proj^T: kind 1 = three bf16 terms (gemm_bf16x3.hpp), 2 = pre-tiled column-scaled fp16 pair (gemm_f16x2_v2.hpp)
     int split_kind;
@@ -74,8 +76,6 @@ struct TileDev {
     int layer, m0, n0, pad;  // pad: split-K slice index (low-rank phase 1)
 };
 
-constexpr int LR_REDUCE_CHUNK = 2048;   // elements per workgroup of the slab reduce (many small blocks: T is small)
-constexpr int LR_KCHUNK_DEFAULT = 512;  // K extent of one low-rank phase-1 tile (the plan may pick another)
 
 struct ChunkDev {
     int tensor;
@@ -400,10 +400,30 @@ __global__ __launch_bounds__(256, 2) void nsgp_project_single_kernel(const float
     else store_tile<FAST, false>(out, cols, rows, cols, m0, n0, acc, scale);
 }
 
-// ---- low-rank form:  p += c * (u - (u U) U^T),  u = scale*S,  U = V[:, :r]  ------------------------
-// Same result as u @ (c * V_tail V_tail^T) up to the orthogonality error of V, in 4*Cout*D*r FLOP.
-// Phase 1: T = u U as split-K slabs (K chunks of 512 so that the skinny [Cout x r] product still fills
-// the chip); a deterministic reduce sums the slabs; phase 2: p += c*(u - T U^T), K = r.
+// ---- low-rank form:  p += c * (u - (u U) U^T),  u = scale*S,  U = the r removed directions ([D x r], r <= 128) ----
+// The north star's own form (g <- g - U (U^T g)).  It is used for projectors the optimizer BUILT ITSELF in the head form
+// P = c * (I - U U^T) (nsgp_build_projector_head, from the orthonormalised top-r eigenvectors): for those the dense u @ P
+// and this form are the same function of (u, U) up to the fp32 rounding of P's entries, and the step costs 4*Cout*D*r
+// FLOP and NO projector traffic instead of 2*Cout*D^2 FLOP and D^2 projector bytes -- the step becomes HBM-bound on the
+// update itself.  Everything is exact fp32 on v_mfma_f32_32x32x2_f32 (lane l supplies A[i = l & 31][k'] and
+// B[k'][j = l & 31], k' = l >> 5): at r <= 128 the matrix work is a few GFLOP per step and hides under the memory stream.
+// Both launches serve every rank class (rpad = 32 .. 128) of a plan at once.
+//
+//   launch T  (nsgp_lr_t_kernel):      T[32 rows x rpad] = scale * (S U).  One workgroup of 12 waves per (32-row block,
+//             K range s of the layer's S): wave w takes the 32-column block jb = w % NJ of U (NJ = rpad / 32) and the
+//             K slice w / NJ of the range, so a wave holds ONE 32 x 32 accumulator whatever the rank.  Each lane loads
+//             16 B of its row per k8 step straight into the MFMA's A register (k = 8t + 4h + e on step e: ANY assignment
+//             of k to (step, lane half) is a valid contraction order as long as B uses the same one); U comes as k-quads
+//             [D/4][rpad][4], so a lane's B operand for four MFMAs is one coalesced 16-byte load.  The slices of a
+//             workgroup are summed in slice order through LDS; with S > 1 the result is a slab and a small launch
+//             (nsgp_lr_reduce_kernel) sums a layer's S slabs in range order -- bitwise deterministic.  S is chosen per layer
+//             so that no workgroup carries more than ~5 us of MFMAs (the 512 x 4608 layers would otherwise be 48 long
+//             workgroups).  (A "last workgroup to arrive sums the slabs" variant needs an agent-scope release / acquire
+//             per workgroup -- an L2 write-back + invalidate on a multi-XCD part -- and measured 0.77 ms.)
+//   launch A  (nsgp_lr_apply_kernel):  p += c * (scale*S - T U^T), K = rpad.  One workgroup per (32 rows x <= 256
+//             columns), the four waves on adjacent 32-column blocks: a wave loads S and p in the (transposed) MFMA C layout
+//             as 16-byte pieces, T and U rows as 16-byte fragments (L1 / L2 hits), does rpad/2 MFMAs and writes p.
+//             HBM-bound: 12 bytes per element.
 template <int OPT>
 __device__ __forceinline__ void lowrank_source(const LayerDev& L, const DynBlock* dyn, const float*& A, float& scale) {
     if (OPT == NSGP_OPT_SGD) {
@@ -416,93 +436,182 @@ __device__ __forceinline__ void lowrank_source(const LayerDev& L, const DynBlock
     }
 }
 
+constexpr int LRT_WAVES = 12;        // divisible by every NJ = 1 .. 4
+constexpr int LRA_COLS = 256;        // columns of one apply workgroup
+constexpr int LR_MAX_RANK = 128;
+constexpr int LR_TILE_LD = 36;       // floats per row of a [32 x 32] LDS tile: 144 B, so that 8 lanes reading 16 B of 8 consecutive rows cover all 32 banks
+constexpr int LR_TILE = 32 * LR_TILE_LD;
+
+typedef __attribute__((address_space(3))) f32x4 lf32x4;
+
+__device__ __forceinline__ f32x4 load4_a4(const float* p) {
+    const f32x4_a4 v = *(const gf32x4_a4*)p;
+    return f32x4{v[0], v[1], v[2], v[3]};
+}
+__device__ __forceinline__ void lds_put4(float* tile, int off, f32x4 v) { *(lf32x4*)((__attribute__((address_space(3))) float*)tile + off) = v; }
+__device__ __forceinline__ f32x4 lds_get4(const float* tile, int off) { return *(const lf32x4*)((const __attribute__((address_space(3))) float*)tile + off); }
+
+// Global <-> MFMA layout goes through a wave-private [32 rows x 32 floats] LDS tile: in memory a wave-instruction covers 8 rows
+// x 128 contiguous bytes (lane l: row l >> 3 (+ 8 per piece), 16-byte chunk l & 7 -- whole cache lines, each touched once),
+// the MFMA wants lane (i = l & 31, h = l >> 5) to hold 16 bytes of row i.  (Loading in the MFMA layout directly -- 32 rows x 32
+// bytes per instruction, four instructions per line -- measured 0.12 ms for the apply launch against the stream's 0.06.)
+
 template <int OPT>
-__global__ __launch_bounds__(256, 2) void nsgp_lowrank_p1_kernel(const TileDev* __restrict__ tiles,
-                                                                 const LayerDev* __restrict__ layers,
-                                                                 const DynBlock* __restrict__ dyn) {
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    const TileDev t = tiles[blockIdx.x];
+__global__ __launch_bounds__(LRT_WAVES * 64) void nsgp_lr_t_kernel(const TileDev* __restrict__ units, const LayerDev* __restrict__ layers,
+                                                                  const DynBlock* __restrict__ dyn) {
+    __shared__ __attribute__((aligned(16))) float lds[LRT_WAVES * LR_TILE];   // the waves' A tiles; afterwards the 12 partial T blocks (1024 floats each)
+    const TileDev t = units[blockIdx.x];           // m0 = first row, pad = K range index s
     const LayerDev L = layers[t.layer];
     const float* A;
     float scale;
     lowrank_source<OPT>(L, dyn, A, scale);
-    const int k0 = t.pad * L.kchunk;
-    const int k1 = min(k0 + L.kchunk, L.cols);
-    f32x16 acc[2][2];
-    zero_acc(acc);
-    float ra[2][4][4], rb[2][4][4];
-    const bool a_fast = ((uintptr_t)A & 15u) == 0;
-    mfma_pipeline<false>(
-        (k1 - k0) / BK, smem, acc,
-        [&](int kt, auto s) {
-            constexpr int S = decltype(s)::value;
-            if (a_fast) stage_rows<true>(A, L.cols, L.rows, L.cols, t.m0, k0 + kt * BK, ra[S]);
-            else stage_rows<false>(A, L.cols, L.rows, L.cols, t.m0, k0 + kt * BK, ra[S]);
-            stage_kn<true>(L.basis, L.cols, L.cols, L.cols, k0 + kt * BK, t.n0, rb[S]);
-        },
-        [&](float* img, int, auto s) { write_rows(img, ra[decltype(s)::value]); },
-        [&](float* img, int, auto s) { write_kn(img, rb[decltype(s)::value]); });
-    float* slab = L.slabs + (long)t.pad * L.rows * L.rpad;
-    acc_to_lds(smem, acc);
-    for_each_row4(smem, [&](int r, int col, float4 v) {
-        f32x4 q;
-        q[0] = scale * v.x; q[1] = scale * v.y; q[2] = scale * v.z; q[3] = scale * v.w;
-        *(gf32x4*)(slab + (long)(t.m0 + r) * L.rpad + t.n0 + col) = q;
-    });
-}
-
-__global__ __launch_bounds__(256) void nsgp_lowrank_reduce_kernel(const ChunkDev* __restrict__ chunks,
-                                                                  const LayerDev* __restrict__ layers) {
-    const ChunkDev c = chunks[blockIdx.x];
-    const LayerDev L = layers[c.tensor];
-    const long n = (long)L.rows * L.rpad;
-    const long end = (c.start + LR_REDUCE_CHUNK < n) ? c.start + LR_REDUCE_CHUNK : n;
-    for (long i = c.start + (long)threadIdx.x * 4; i < end; i += 256 * 4) {   // rpad % 128 == 0 -> n % 4 == 0
-        f32x4 s = *(const gf32x4*)(L.slabs + i);
-        for (int k = 1; k < L.nsplit; ++k) s += *(const gf32x4*)(L.slabs + (long)k * n + i);
-        *(gf32x4*)(L.T + i) = s;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int i = lane & 31, h = lane >> 5, r8 = lane >> 3, ch = lane & 7;
+    const int NJ = L.rpad >> 5, ksl = LRT_WAVES / NJ;
+    const int jb = wave % NJ, ks = wave / NJ;
+    const int ngroups = L.cols >> 5;               // groups of 32 k = one 128-byte line per row
+    const int per = (ngroups + L.nsplit * ksl - 1) / (L.nsplit * ksl);
+    const int g0 = min(ngroups, (t.pad * ksl + ks) * per), g1 = min(ngroups, g0 + per);
+    float* tile = lds + wave * LR_TILE;
+    const float* abase = A + (long)(t.m0 + r8) * L.cols + 4 * ch;          // + 8 it rows, + 32 g columns
+    const long a8 = 8L * L.cols;
+    const float* ub = L.ukq + ((long)h * L.rpad + jb * 32 + i) * 4;        // quad 8 g + 2 s + h, column 32 jb + i
+    const long qs = 2L * L.rpad * 4, qg = 8L * L.rpad * 4;                 // floats per k8 step, per group
+    f32x16 acc;
+#pragma unroll
+    for (int v = 0; v < 16; ++v) acc[v] = 0.0f;
+    f32x4 a[2][4], b[2][4];
+    auto load = [&](int g, auto set_) {
+        constexpr int set = decltype(set_)::value;
+#pragma unroll
+        for (int it = 0; it < 4; ++it) a[set][it] = load4_a4(abase + it * a8 + 32L * g);
+#pragma unroll
+        for (int st = 0; st < 4; ++st) b[set][st] = *(const gf32x4*)(ub + g * qg + st * qs);
+    };
+    auto mma = [&](auto set_) {
+        constexpr int set = decltype(set_)::value;
+#pragma unroll
+        for (int it = 0; it < 4; ++it) lds_put4(tile, (r8 + 8 * it) * LR_TILE_LD + 4 * ch, a[set][it]);
+        f32x4 f[4];
+#pragma unroll
+        for (int st = 0; st < 4; ++st) f[st] = lds_get4(tile, i * LR_TILE_LD + 4 * (2 * st + h));      // k = 32 g + 8 st + 4 h + e
+#pragma unroll
+        for (int st = 0; st < 4; ++st)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(f[st][e], b[set][st][e], acc, 0, 0, 0);
+    };
+    if (g0 < g1) {
+        load(g0, IC<0>{});
+        int g = g0;
+        for (; g + 2 < g1; g += 2) {
+            load(g + 1, IC<1>{});
+            mma(IC<0>{});
+            load(g + 2, IC<0>{});
+            mma(IC<1>{});
+        }
+        if (g + 1 < g1) load(g + 1, IC<1>{});
+        mma(IC<0>{});
+        if (g + 1 < g1) mma(IC<1>{});
+    }
+    // the K slices of each column block, summed in slice order (deterministic)
+    __syncthreads();                               // every wave is done with its A tile: the buffer becomes the 12 partial blocks
+    float* mine = lds + wave * 1024;
+#pragma unroll
+    for (int v = 0; v < 16; ++v) mine[acc_row(v, lane) * 32 + i] = acc[v];
+    __syncthreads();
+    float* dst = (L.nsplit > 1) ? L.slabs + (long)t.pad * L.rows * L.rpad : L.T;
+    const float osc = (L.nsplit > 1) ? 1.0f : scale;
+    for (int idx = threadIdx.x; idx < NJ * 1024; idx += LRT_WAVES * 64) {
+        const int j = idx >> 10, e = idx & 1023;                  // column block, element (row e >> 5, column e & 31)
+        float sum = lds[j * 1024 + e];                             // wave = ks * NJ + j
+        for (int k = 1; k < ksl; ++k) sum += lds[(k * NJ + j) * 1024 + e];
+        as_global(dst)[(long)(t.m0 + (e >> 5)) * L.rpad + j * 32 + (e & 31)] = osc * sum;
     }
 }
 
+// T = scale * (sum of the K-range slabs, in range order) for the layers that were split (deterministic; a few MB in all)
+constexpr int LR_REDUCE_CHUNK = 1024;
+__global__ __launch_bounds__(256) void nsgp_lr_reduce_kernel(const ChunkDev* __restrict__ chunks, const LayerDev* __restrict__ layers,
+                                                             const DynBlock* __restrict__ dyn, int optimizer) {
+    const ChunkDev c = chunks[blockIdx.x];
+    const LayerDev L = layers[c.tensor];
+    const float scale = (optimizer == NSGP_OPT_SGD) ? -dyn->hyper[L.hyper].lr : 1.0f;
+    const long n = (long)L.rows * L.rpad, i = c.start + (long)threadIdx.x * 4;      // n % 1024 == 0 (rows % 32 == 0, rpad % 32 == 0)
+    f32x4 part[16];
+#pragma unroll
+    for (int k = 0; k < 16; ++k)
+        if (k < L.nsplit) part[k] = *(const gf32x4*)(L.slabs + (long)k * n + i);    // all loads in flight together
+    f32x4 sum = part[0];
+#pragma unroll
+    for (int k = 1; k < 16; ++k)
+        if (k < L.nsplit) sum += part[k];
+    *(gf32x4*)(L.T + i) = scale * sum;
+}
+
 template <int OPT>
-__global__ __launch_bounds__(256, 2) void nsgp_lowrank_p2_kernel(const TileDev* __restrict__ tiles,
-                                                                 const LayerDev* __restrict__ layers,
-                                                                 const DynBlock* __restrict__ dyn) {
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    const TileDev t = tiles[blockIdx.x];
+__global__ __launch_bounds__(256) void nsgp_lr_apply_kernel(const TileDev* __restrict__ units, const LayerDev* __restrict__ layers,
+                                                            const DynBlock* __restrict__ dyn) {
+    __shared__ __attribute__((aligned(16))) float t_lds[32 * (LR_MAX_RANK + 4)];      // T[m0 .. m0+32][rpad], rows padded by 4 floats
+    __shared__ __attribute__((aligned(16))) float w_lds[4 * LR_TILE];                  // per wave: a U chunk, then the output block
+    const TileDev t = units[blockIdx.x];           // m0, n0, pad = columns of this workgroup (<= 256, a multiple of 32)
     const LayerDev L = layers[t.layer];
     const float* A;
     float scale;
     lowrank_source<OPT>(L, dyn, A, scale);
-    f32x16 acc[2][2];
-    zero_acc(acc);
-    float ra[2][4][4], rb[2][4][4];
-    mfma_pipeline<true>(
-        (L.rank + BK - 1) / BK, smem, acc,
-        [&](int kt, auto s) {
-            constexpr int S = decltype(s)::value;
-            stage_rows<true>(L.T, L.rpad, L.rows, L.rpad, t.m0, kt * BK, ra[S]);          // T[m][k]
-            stage_rows<true>(L.basis, L.cols, L.cols, L.cols, t.n0, kt * BK, rb[S]);       // U[n][k] = V[n][k]
-        },
-        [&](float* img, int kt, auto s) { write_rows_khi(img, ra[decltype(s)::value], kt * BK, L.rank); },
-        [&](float* img, int kt, auto s) { write_rows_khi(img, rb[decltype(s)::value], kt * BK, L.rank); });
-    // p += c * (scale*S - T U^T), 16 bytes per lane (the K loop is only r/32 steps long: the epilogue,
-    // three global arrays per element, would otherwise dominate this kernel)
-    __syncthreads();                       // every wave is done reading the K-loop images
-    acc_to_lds(smem, acc);
-    __builtin_amdgcn_s_waitcnt(0xc07f);    // lgkmcnt(0): this wave's own LDS writes have landed
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int i = lane & 31, h = lane >> 5, r8 = lane >> 3, ch = lane & 7;
     const float c = L.basis_scale;
-    for_each_row4(smem, [&](int r, int col, float4 v) {
-        const long idx = (long)(t.m0 + r) * L.cols + t.n0 + col;
-        const f32x4 a = *(const gf32x4*)(A + idx);
-        gf32x4* pp = (gf32x4*)(L.p + idx);
-        f32x4 pv = *pp;
-        pv[0] = pv[0] + c * (scale * a[0] - v.x);
-        pv[1] = pv[1] + c * (scale * a[1] - v.y);
-        pv[2] = pv[2] + c * (scale * a[2] - v.z);
-        pv[3] = pv[3] + c * (scale * a[3] - v.w);
-        *pp = pv;
-    });
+    const int NJ = L.rpad >> 5, tld = L.rpad + 4;
+    for (int x = threadIdx.x; x < 8 * L.rpad; x += 256) {                               // 32 rows x rpad / 4 pieces, contiguous in memory
+        const int row = x / (L.rpad >> 2), c4 = x - row * (L.rpad >> 2);
+        lds_put4(t_lds, row * tld + 4 * c4, *(const gf32x4*)(L.T + (long)t.m0 * L.rpad + 4L * x));
+    }
+    __syncthreads();
+    float* tile = w_lds + wave * LR_TILE;
+    // The MFMA computes the TRANSPOSED block C[n][m] = sum_k U[n][k] T[m][k] (A operand = U rows, B operand = T rows): lane
+    // (i, h) then holds, for row m = m0 + i, the columns n + 8 g + 4 h + (0..3), g = 0..3 -- four 16-byte pieces for the tile.
+    // The four waves take ADJACENT 32-column blocks (512 contiguous bytes per row at a time), then the next 128 columns.
+    for (int n = t.n0 + 32 * wave; n < t.n0 + t.pad; n += 128) {
+        const long off = (long)(t.m0 + r8) * L.cols + n + 4 * ch;
+        const long r8s = 8L * L.cols;
+        f32x4 av[4], pv[4];
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+            av[it] = load4_a4(A + off + it * r8s);
+            pv[it] = *(const gf32x4*)(L.p + off + it * r8s);
+        }
+        f32x16 acc;
+#pragma unroll
+        for (int v = 0; v < 16; ++v) acc[v] = 0.0f;
+        const float* ubase = L.urm + (long)(n + r8) * L.rpad + 4 * ch;
+        for (int jb = 0; jb < NJ; ++jb) {                              // 32 k at a time
+            f32x4 u4[4];
+#pragma unroll
+            for (int it = 0; it < 4; ++it) u4[it] = *(const gf32x4*)(ubase + (long)(8 * it) * L.rpad + 32 * jb);
+#pragma unroll
+            for (int it = 0; it < 4; ++it) lds_put4(tile, (r8 + 8 * it) * LR_TILE_LD + 4 * ch, u4[it]);
+            f32x4 fu[4], ft[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                fu[q] = lds_get4(tile, i * LR_TILE_LD + 4 * (2 * q + h));              // U[n + i][32 jb + 8 q + 4 h ..]
+                ft[q] = lds_get4(t_lds, i * tld + 32 * jb + 4 * (2 * q + h));          // T[m0 + i][32 jb + 8 q + 4 h ..]
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fu[q][e], ft[q][e], acc, 0, 0, 0);
+        }
+#pragma unroll
+        for (int g = 0; g < 4; ++g) lds_put4(tile, i * LR_TILE_LD + 8 * g + 4 * h, f32x4{acc[4 * g], acc[4 * g + 1], acc[4 * g + 2], acc[4 * g + 3]});
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+            const f32x4 cv = lds_get4(tile, (r8 + 8 * it) * LR_TILE_LD + 4 * ch);
+            f32x4 o;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[e] = pv[it][e] + c * (scale * av[it][e] - cv[e]);
+            *(gf32x4*)(L.p + off + it * r8s) = o;
+        }
+    }
 }
 
 // ---- host: plan ---------------------------------------------------------------
@@ -535,9 +644,10 @@ struct nsgp_plan {
     TensorDev* d_tensors = nullptr;
     LayerDev* d_layers = nullptr;
     TileDev* d_tiles = nullptr;  // dense fast tiles | dense generic tiles | low-rank phase-1 | phase-2
-    int n_tiles_lr1 = 0, n_tiles_lr2 = 0, n_chunks_lr = 0, n_lowrank = 0;
-    double lowrank_flops = 0;
+    int n_tiles_lr1 = 0, n_tiles_lr2 = 0, n_lowrank = 0;    // low-rank: workgroups of launch T and of launch A
+    int n_chunks_lr = 0;
     ChunkDev* d_chunks_lr = nullptr;
+    double lowrank_flops = 0;
     ChunkDev* d_chunks = nullptr;
     size_t dyn_bytes = 0;
     char* h_dyn[NSLOT] = {nullptr, nullptr, nullptr, nullptr};  // pinned
@@ -558,37 +668,25 @@ static bool tensor_v2(const nsgp_tensor_t& t) {
     return tensor_fast(t) && t.split_kind == 2 && t.proj_split && aligned16(t.proj_split) && aligned16(t.param) && aligned16(t.state0);
 }
 
-// low-rank form: needs the fast shape, an aligned basis, and r <= D/4 (else the dense GEMM is cheaper)
-static bool tensor_lowrank(const nsgp_tensor_t& t) {
-    return t.basis && t.rank > 0 && 4 * (long)t.rank <= t.cols && t.rows % BM == 0 && t.cols % BN == 0 &&
-           aligned16(t.basis) && aligned16(t.param) && t.proj;
-}
-static int lr_rpad(int rank) { return (rank + BN - 1) / BN * BN; }
-static int lr_nsplit(int cols, int kchunk) { return (cols + kchunk - 1) / kchunk; }
-
-// One K chunk for all low-rank layers of a plan: the candidate whose phase-1 grid makes the fewest,
-// fullest rounds on the 512 workgroup slots (cost model: rounds x (fixed tile overhead + K-steps)).
-static int lr_pick_kchunk(const nsgp_tensor_t* tensors, int n) {
-    static const int cand[] = {512, 768, 1024, 1536};   // >= 512: every extra slab is re-read by the reduce
-    int best = LR_KCHUNK_DEFAULT;
-    double best_cost = 1e300;
-    for (int kc : cand) {
-        long tiles = 0;
-        int maxsteps = 0;
-        for (int i = 0; i < n; ++i) {
-            const nsgp_tensor_t& t = tensors[i];
-            if (!tensor_lowrank(t)) continue;
-            tiles += (long)(t.rows / BM) * (lr_rpad(t.rank) / BN) * lr_nsplit(t.cols, kc);
-            maxsteps = std::max(maxsteps, std::min(kc, t.cols) / BK);
-        }
-        if (tiles == 0) return LR_KCHUNK_DEFAULT;
-        const double rounds = std::ceil(tiles / 512.0);
-        const double cost = rounds * (3.0 + maxsteps);   // in K-step units; 3 ~ prologue + epilogue of a tile
-        if (cost < best_cost) { best_cost = cost; best = kc; }
-    }
-    return best;
-}
 static size_t pad256(size_t x) { return (x + 255) & ~(size_t)255; }
+
+// low-rank form: a head-form projector (the caller vouches that proj == basis_scale * (I - U U^T)), r <= 128, 32-aligned shape
+static bool tensor_lowrank(const nsgp_tensor_t& t) {
+    return t.basis && t.basis_rows && t.rank > 0 && t.rank <= LR_MAX_RANK && t.rows % 32 == 0 && t.cols % 32 == 0 &&
+           aligned16(t.basis) && aligned16(t.basis_rows) && t.proj;
+}
+static int lr_rpad(int rank) { return (rank + 31) / 32 * 32; }
+// K ranges of a low-rank layer's T launch: a workgroup's MFMA time is (D/8 k8-steps) x 4 MFMAs x 64 clk x NJ column blocks
+// over 4 SIMDs = D * NJ * 8 clk; keep it under ~12,000 clk (5 us)
+static int lr_nsplit(int cols, int rank) {
+    const long clk = (long)cols * (lr_rpad(rank) / 32) * 8;
+    return (int)std::max<long>(1, std::min<long>(16, (clk + 11999) / 12000));
+}
+static size_t lr_workspace(const nsgp_tensor_t& t) {
+    const size_t one = pad256((size_t)t.rows * lr_rpad(t.rank) * 4);
+    const int S = lr_nsplit(t.cols, t.rank);
+    return one + (S > 1 ? (size_t)S * one : 0);
+}
 
 extern "C" size_t nsgp_plan_workspace_bytes(const nsgp_tensor_t* tensors, int n, int optimizer) {
     if (!tensors) return 0;
@@ -598,7 +696,7 @@ extern "C" size_t nsgp_plan_workspace_bytes(const nsgp_tensor_t* tensors, int n,
         if (!t.proj) continue;
         if (optimizer == NSGP_OPT_ADAM) s += pad256((size_t)t.numel * 4);
         if (tensor_v2(t) && !tensor_lowrank(t)) s += pad256(v2_operand_bytes(t.rows, t.cols)) + pad256((size_t)t.rows * 4);
-        if (tensor_lowrank(t)) s += pad256((size_t)t.rows * lr_rpad(t.rank) * 4) * (1 + lr_nsplit(t.cols, 256));  // worst case split
+        if (tensor_lowrank(t)) s += lr_workspace(t);
     }
     return s;
 }
@@ -620,7 +718,6 @@ extern "C" int nsgp_plan_create(nsgp_plan_t** out, const nsgp_tensor_t* tensors,
     int split_kind = 0;
     double flops = 0, bytes = 0, lr_flops = 0;
     int n_lowrank = 0;
-    const int lr_kchunk = lr_pick_kchunk(tensors, n);
     size_t ws_off = 0;
     for (int i = 0; i < n; ++i) {
         const nsgp_tensor_t& t = tensors[i];
@@ -637,8 +734,9 @@ extern "C" int nsgp_plan_create(nsgp_plan_t** out, const nsgp_tensor_t* tensors,
                 d.u = reinterpret_cast<float*>(static_cast<char*>(workspace) + ws_off);
                 ws_off += ((size_t)t.numel * 4 + 255) & ~(size_t)255;
             }
-            LayerDev L{t.param, t.state0, d.u, t.proj, i, t.rows, t.cols, t.hyper, nullptr, nullptr, nullptr, 0, 0, 0, 0, 1.0f,
-                       t.proj_split, t.split_kind, 0, nullptr, nullptr, nullptr};
+            LayerDev L{};
+            L.p = t.param; L.s0 = t.state0; L.u = d.u; L.proj = t.proj; L.tensor = i; L.rows = t.rows; L.cols = t.cols; L.hyper = t.hyper;
+            L.basis_scale = 1.0f; L.split = t.proj_split; L.split_kind = t.split_kind;
             if (tensor_v2(t) && !tensor_lowrank(t)) {
                 // the split copy carries its column scales behind the planes: [D x D x 4 B][scale: D floats][1/scale: D floats]
                 L.cinv = reinterpret_cast<const float*>(static_cast<const char*>(t.proj_split) + v2_operand_bytes(t.cols, t.cols)) + t.cols;
@@ -650,16 +748,16 @@ extern "C" int nsgp_plan_create(nsgp_plan_t** out, const nsgp_tensor_t* tensors,
                 L.rinv = d.rinv;
             }
             if (tensor_lowrank(t)) {
-                L.basis = t.basis;
+                L.ukq = t.basis;
+                L.urm = t.basis_rows;
                 L.rank = t.rank;
                 L.rpad = lr_rpad(t.rank);
-                L.kchunk = lr_kchunk;
-                L.nsplit = lr_nsplit(t.cols, lr_kchunk);
                 L.basis_scale = t.basis_scale;
+                L.nsplit = lr_nsplit(t.cols, t.rank);
                 const size_t one = pad256((size_t)t.rows * L.rpad * 4);
                 L.T = reinterpret_cast<float*>(static_cast<char*>(workspace) + ws_off);
-                L.slabs = reinterpret_cast<float*>(static_cast<char*>(workspace) + ws_off + one);
-                ws_off += one * (1 + L.nsplit);
+                if (L.nsplit > 1) L.slabs = reinterpret_cast<float*>(static_cast<char*>(workspace) + ws_off + one);
+                ws_off += lr_workspace(t);
                 lr_flops += 4.0 * t.rows * (double)t.cols * t.rank;
                 ++n_lowrank;
             }
@@ -761,24 +859,26 @@ extern "C" int nsgp_plan_create(nsgp_plan_t** out, const nsgp_tensor_t* tensors,
     P->n_tiles_generic = (int)gen_tiles.size();
     P->gemm_flops = flops;
     P->bytes = bytes;
-    // low-rank tiles: phase 1 (T slabs: [rows x rpad] per K chunk), phase 2 (p tiles, K = r); both
-    // in descending-cost order (phase 1 tiles all cost one K chunk; phase 2 cost ~ r)
+    // low-rank units.  Launch T: one workgroup per (32-row block, K range), longest K range first; launch A: one workgroup per
+    // (32 rows x <= 256 columns), widest rank first.
     std::vector<TileDev> lr1, lr2;
-    std::vector<ChunkDev> lr_chunks;
+    std::vector<ChunkDev> lr_chunks;      // slab reduce of the layers with more than one K range
     {
         std::vector<int> lo;
         for (size_t li = 0; li < ld.size(); ++li)
             if (ld[li].rank > 0) lo.push_back((int)li);
-        std::stable_sort(lo.begin(), lo.end(), [&](int a, int b) { return ld[a].rank > ld[b].rank; });
-        for (int li : lo) {
-            const LayerDev& L = ld[li];
-            for (int ks = 0; ks < L.nsplit; ++ks)
-                for (int j = 0; j < L.rpad / BN; ++j)
-                    for (int m = 0; m < L.rows / BM; ++m) lr1.push_back(TileDev{li, m * BM, j * BN, ks});
-            for (int j = 0; j < L.cols / BN; ++j)
-                for (int m = 0; m < L.rows / BM; ++m) lr2.push_back(TileDev{li, m * BM, j * BN, 0});
-            for (long st = 0; st < (long)L.rows * L.rpad; st += LR_REDUCE_CHUNK) lr_chunks.push_back(ChunkDev{li, 0, st});
-        }
+        auto t_cost = [&](int li) { return (long)ld[li].cols * ld[li].rpad / ld[li].nsplit; };
+        std::stable_sort(lo.begin(), lo.end(), [&](int a, int b) { return t_cost(a) > t_cost(b); });
+        for (int li : lo)
+            for (int m = 0; m < ld[li].rows; m += 32)
+                for (int sp = 0; sp < ld[li].nsplit; ++sp) lr1.push_back(TileDev{li, m, 0, sp});
+        for (int li : lo)
+            if (ld[li].nsplit > 1)
+                for (long st = 0; st < (long)ld[li].rows * ld[li].rpad; st += LR_REDUCE_CHUNK) lr_chunks.push_back(ChunkDev{li, 0, st});
+        std::stable_sort(lo.begin(), lo.end(), [&](int a, int b) { return ld[a].rpad > ld[b].rpad; });
+        for (int li : lo)
+            for (int m = 0; m < ld[li].rows; m += 32)
+                for (int n0 = 0; n0 < ld[li].cols; n0 += LRA_COLS) lr2.push_back(TileDev{li, m, n0, std::min(LRA_COLS, ld[li].cols - n0)});
     }
     std::vector<TileDev> all_tiles(fast_tiles);
     all_tiles.insert(all_tiles.end(), gen_tiles.begin(), gen_tiles.end());
@@ -826,9 +926,7 @@ extern "C" int nsgp_plan_create(nsgp_plan_t** out, const nsgp_tensor_t* tensors,
         for (int s = 0; s < NSLOT; ++s) fprintf(stderr, "[nsgp alloc]   slot %d: pinned %p device %p\n", s, (void*)P->h_dyn[s], (void*)P->d_dyn[s]);
     }
     int rc;
-    if ((rc = enable_big_lds(nsgp_lowrank_p1_kernel<NSGP_OPT_SGD>)) || (rc = enable_big_lds(nsgp_lowrank_p1_kernel<NSGP_OPT_ADAM>)) ||
-        (rc = enable_big_lds(nsgp_lowrank_p2_kernel<NSGP_OPT_SGD>)) || (rc = enable_big_lds(nsgp_lowrank_p2_kernel<NSGP_OPT_ADAM>)) ||
-        (rc = enable_big_lds(nsgp_project_kernel<NSGP_OPT_SGD, true>)) || (rc = enable_big_lds(nsgp_project_kernel<NSGP_OPT_SGD, false>)) ||
+    if ((rc = enable_big_lds(nsgp_project_kernel<NSGP_OPT_SGD, true>)) || (rc = enable_big_lds(nsgp_project_kernel<NSGP_OPT_SGD, false>)) ||
         (rc = enable_big_lds(nsgp_project_kernel<NSGP_OPT_ADAM, true>)) || (rc = enable_big_lds(nsgp_project_kernel<NSGP_OPT_ADAM, false>)) ||
         (rc = enable_big_lds(nsgp_project_kernel<NSGP_OPT_SGD, true, 1>)) || (rc = enable_big_lds(nsgp_project_kernel<NSGP_OPT_ADAM, true, 1>)) ||
         (rc = enable_v2_lds(nsgp_project_v2_kernel<NSGP_OPT_SGD>)) || (rc = enable_v2_lds(nsgp_project_v2_kernel<NSGP_OPT_ADAM>))) {
@@ -977,16 +1075,18 @@ extern "C" int nsgp_plan_step(nsgp_plan_t* P, float* const* grads, const nsgp_hy
         const TileDev* t1 = P->d_tiles + P->n_tiles_fast + P->n_tiles_generic;
         const TileDev* t2 = t1 + P->n_tiles_lr1;
         if (P->optimizer == NSGP_OPT_SGD)
-            hipLaunchKernelGGL(nsgp_lowrank_p1_kernel<NSGP_OPT_SGD>, dim3(P->n_tiles_lr1), dim3(THREADS), SMEM_BYTES, stream, t1, P->d_layers, d);
+            hipLaunchKernelGGL(nsgp_lr_t_kernel<NSGP_OPT_SGD>, dim3(P->n_tiles_lr1), dim3(LRT_WAVES * 64), 0, stream, t1, P->d_layers, d);
         else
-            hipLaunchKernelGGL(nsgp_lowrank_p1_kernel<NSGP_OPT_ADAM>, dim3(P->n_tiles_lr1), dim3(THREADS), SMEM_BYTES, stream, t1, P->d_layers, d);
+            hipLaunchKernelGGL(nsgp_lr_t_kernel<NSGP_OPT_ADAM>, dim3(P->n_tiles_lr1), dim3(LRT_WAVES * 64), 0, stream, t1, P->d_layers, d);
         NSGP_LAUNCH_CHECK();
-        hipLaunchKernelGGL(nsgp_lowrank_reduce_kernel, dim3(P->n_chunks_lr), dim3(256), 0, stream, P->d_chunks_lr, P->d_layers);
-        NSGP_LAUNCH_CHECK();
+        if (P->n_chunks_lr > 0) {
+            hipLaunchKernelGGL(nsgp_lr_reduce_kernel, dim3(P->n_chunks_lr), dim3(256), 0, stream, P->d_chunks_lr, P->d_layers, d, P->optimizer);
+            NSGP_LAUNCH_CHECK();
+        }
         if (P->optimizer == NSGP_OPT_SGD)
-            hipLaunchKernelGGL(nsgp_lowrank_p2_kernel<NSGP_OPT_SGD>, dim3(P->n_tiles_lr2), dim3(THREADS), SMEM_BYTES, stream, t2, P->d_layers, d);
+            hipLaunchKernelGGL(nsgp_lr_apply_kernel<NSGP_OPT_SGD>, dim3(P->n_tiles_lr2), dim3(256), 0, stream, t2, P->d_layers, d);
         else
-            hipLaunchKernelGGL(nsgp_lowrank_p2_kernel<NSGP_OPT_ADAM>, dim3(P->n_tiles_lr2), dim3(THREADS), SMEM_BYTES, stream, t2, P->d_layers, d);
+            hipLaunchKernelGGL(nsgp_lr_apply_kernel<NSGP_OPT_ADAM>, dim3(P->n_tiles_lr2), dim3(256), 0, stream, t2, P->d_layers, d);
         NSGP_LAUNCH_CHECK();
     }
     if (prof) {

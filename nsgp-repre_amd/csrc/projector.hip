@@ -87,6 +87,52 @@ __global__ __launch_bounds__(256) void nsgp_divide_kernel(float* __restrict__ P,
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) P[i] = P[i] / nrm;
 }
 
+// Head form: P = I - U U^T from the r REMOVED directions, U [D][rpad] row-major fp32 (columns >= rank zero, rpad a
+// multiple of 32, <= 128), D % 32 == 0.  One wave per (32 rows x 256 columns) strip on v_mfma_f32_32x32x2_f32 with K = rpad;
+// P[m][n] and P[n][m] are the same k-ordered chain of the same (commuting) products, so P is bit-symmetric.  This is the
+// form the low-rank step applies (projected_step.hip), so `u @ P` and `c (u - (u U) U^T)` agree to the rounding of P's entries.
+template <int NJ>
+__device__ __forceinline__ void projector_head_body(const float* __restrict__ U, float* __restrict__ P, int D, int rpad, int m0, int n0, int ncols) {
+    const int lane = threadIdx.x & 63;
+    const int i = lane & 31, h = lane >> 5;
+    f32x4 ta[4 * NJ];
+    const float* trow = U + (long)(m0 + i) * rpad + 4 * h;
+#pragma unroll
+    for (int q = 0; q < 4 * NJ; ++q) ta[q] = *(const gf32x4*)(trow + 8 * q);
+    for (int n = n0; n < n0 + ncols; n += 32) {
+        f32x4 ub[4 * NJ];
+        const float* urow = U + (long)(n + i) * rpad + 4 * h;
+#pragma unroll
+        for (int q = 0; q < 4 * NJ; ++q) ub[q] = *(const gf32x4*)(urow + 8 * q);
+        f32x16 acc;
+#pragma unroll
+        for (int v = 0; v < 16; ++v) acc[v] = 0.0f;
+#pragma unroll
+        for (int q = 0; q < 4 * NJ; ++q)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ta[q][e], ub[q][e], acc, 0, 0, 0);
+#pragma unroll
+        for (int v = 0; v < 16; ++v) {
+            const int row = m0 + acc_row(v, lane), col = n + i;
+            as_global(P)[(long)row * D + col] = (row == col ? 1.0f : 0.0f) - acc[v];
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void nsgp_projector_head_kernel(const float* __restrict__ U, float* __restrict__ P, int D, int rpad) {
+    const int strips = (D + 255) / 256;
+    const int unit = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (unit >= (D / 32) * strips) return;
+    const int m0 = (unit / strips) * 32, n0 = (unit % strips) * 256;
+    const int ncols = min(256, D - n0);
+    switch (rpad >> 5) {
+        case 1: projector_head_body<1>(U, P, D, rpad, m0, n0, ncols); break;
+        case 2: projector_head_body<2>(U, P, D, rpad, m0, n0, ncols); break;
+        case 3: projector_head_body<3>(U, P, D, rpad, m0, n0, ncols); break;
+        default: projector_head_body<4>(U, P, D, rpad, m0, n0, ncols); break;
+    }
+}
+
 }  // namespace nsgp
 
 using namespace nsgp;
@@ -124,5 +170,30 @@ extern "C" int nsgp_build_projector(const float* V, int D, int first_col, int no
         hipLaunchKernelGGL(nsgp_divide_kernel, dim3(2048), dim3(256), 0, stream, P, n, partial);
         NSGP_LAUNCH_CHECK();
     }
+    return NSGP_OK;
+}
+
+static int normalise_projector(float* P, int D, double* partial, hipStream_t stream) {
+    const long n = (long)D * D;
+    int blocks = (int)std::min<long>(NORM_BLOCKS, (n + 255) / 256);
+    hipLaunchKernelGGL(nsgp_sumsq_partial_kernel, dim3(blocks), dim3(256), 0, stream, P, n, partial);
+    NSGP_LAUNCH_CHECK();
+    hipLaunchKernelGGL(nsgp_norm_final_kernel, dim3(1), dim3(256), 0, stream, partial, blocks);
+    NSGP_LAUNCH_CHECK();
+    hipLaunchKernelGGL(nsgp_divide_kernel, dim3(2048), dim3(256), 0, stream, P, n, partial);
+    NSGP_LAUNCH_CHECK();
+    return NSGP_OK;
+}
+
+extern "C" int nsgp_build_projector_head(const float* U, int D, int rpad, int normalise, float* P, void* scratch,
+                                         size_t scratch_bytes, void* stream_) {
+    if (!U || !P || D <= 0 || D % 32 != 0 || rpad <= 0 || rpad % 32 != 0 || rpad > 128 || !aligned16(U))
+        return fail(NSGP_ERR_INVALID, "nsgp_build_projector_head: bad argument (D=%d rpad=%d; D %% 32 == 0, rpad in {32,64,96,128}, U 16-byte aligned)", D, rpad);
+    if (!scratch || scratch_bytes < nsgp_projector_scratch_bytes(D)) return fail(NSGP_ERR_WORKSPACE, "nsgp_build_projector_head: scratch too small");
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    const int units = (D / 32) * ((D + 255) / 256);
+    hipLaunchKernelGGL(nsgp_projector_head_kernel, dim3((units + 3) / 4), dim3(256), 0, stream, U, P, D, rpad);
+    NSGP_LAUNCH_CHECK();
+    if (normalise) return normalise_projector(P, D, static_cast<double*>(scratch), stream);
     return NSGP_OK;
 }

@@ -107,6 +107,27 @@ def build_projector(V: torch.Tensor, first_col: int, normalise: bool, out: torch
     return out
 
 
+def build_projector_head(U: torch.Tensor, normalise: bool, out: torch.Tensor = None, return_norm: bool = False):
+    """``P = I - U U^T`` (``/ ||P||_F`` if normalise) from the REMOVED directions ``U`` [D x rpad] (orthonormal columns,
+    zero-padded to a multiple of 32, at most 128) -- the projector of SGD_NSCL.py:270-285 written from the other side; the
+    form the low-rank step applies (``nsgp_build_projector_head``)."""
+    lib = _lib.load_library()
+    D, rpad = U.shape
+    fresh = out is None
+    if fresh:
+        out = torch.empty(D, D, dtype=torch.float32, device=U.device)
+    nbytes = lib.nsgp_projector_scratch_bytes(D)
+    scratch = torch.empty(nbytes, dtype=torch.uint8, device=U.device)
+    _lib.check(lib.nsgp_build_projector_head(_dev(U, "U"), D, rpad, int(bool(normalise)), _dev(out, "P"),
+                                             C.c_void_p(scratch.data_ptr()), nbytes, _stream()), "nsgp_build_projector_head")
+    if not fresh:
+        _touched(out)
+    if return_norm:
+        norm = scratch[1024 * 8:1024 * 8 + 4].view(torch.float32)[0] if normalise else torch.ones((), device=U.device)
+        return out, norm
+    return out
+
+
 def cov_accumulate_conv2d(x: torch.Tensor, kernel_size, stride, padding, cov: torch.Tensor = None,
                           workspace: torch.Tensor = None) -> torch.Tensor:
     """``C (+)= X^T X`` with X the implicit unfold of the batch mean --

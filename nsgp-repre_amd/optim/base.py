@@ -8,9 +8,10 @@ the public ``eigens`` / ``transforms`` dicts and the extra param-group key
 
 What differs is *how* a step runs: instead of a Python loop of ~160 x 5 tiny
 elementwise launches plus 50 `torch.mm`, ``step()`` hands one table to
-``nsgp_plan_step`` (C ABI): one multi-tensor HIP kernel + one grouped MFMA GEMM
-(three-term bf16 split by default, fp32 MFMA with ``split_mfma = False``) on the
-current stream.
+``nsgp_plan_step`` (C ABI) on the current stream: one multi-tensor HIP kernel, then -- for projectors this
+optimizer built itself (``get_transforms`` / ``set_basis``) with at most 128 removed directions -- the low-rank
+form ``p += c (u - (u U) U^T)`` (two launches, exact fp32 MFMA, HBM-bound), and for every other projector one
+grouped dense MFMA GEMM ``u @ P`` (two-term fp16 split by default, fp32 MFMA with ``split_mfma = False``).
 """
 import ctypes as C
 import logging
@@ -24,6 +25,9 @@ from .. import _lib, ops
 from .threshold import elbow_index
 
 logger = logging.getLogger("nsgp_repre_amd")
+
+#: largest number of removed directions the low-rank form of the step takes (csrc/projected_step.hip: LR_MAX_RANK)
+LOW_RANK_MAX = 128
 
 #: default of ``optimizer.split_mfma`` (see NSCLOptimizerBase.__init__): False | "bf16x3" | "f16x2" (True = "f16x2")
 SPLIT_MFMA_DEFAULT = "f16x2"
@@ -65,10 +69,16 @@ class NSCLOptimizerBase(Optimizer):
         self.count = 0
         #: mirror the reference's in-place mutation of ``p.grad`` (weight decay / Nesterov add)
         self.mutate_grad = True
-        #: opt-in: apply projectors built by get_transforms in their low-rank form
-        #: p += c*(u - (u U)U^T) (4*Cout*D*r FLOP) when r <= D/4; the dense u @ P is the parity path
-        self.low_rank = False
-        #: with low_rank: orthonormalise the eigenbasis (one Newton-Schulz step) before building P from it
+        #: projectors built by get_transforms / set_basis with r <= LOW_RANK_MAX removed directions (and D % 32 == 0) are built
+        #: in the HEAD form P = c (I - U U^T) from the orthonormalised top-r eigenvectors U, and the step applies them as
+        #: p += c (u - (u U) U^T): 4*Cout*D*r FLOP and no projector traffic instead of 2*Cout*D^2 FLOP + D^2 projector bytes.
+        #: ``transforms[name]`` still holds the dense P (the reference's public attribute); dense u @ P and the low-rank
+        #: form are the same function of (u, U) up to the rounding of P's entries.  False = always build V_tail V_tail^T and
+        #: always run the dense GEMM (the reference's literal formula).  Projectors assigned from outside
+        #: (``transforms[name] = P``) always take the dense GEMM.
+        self.low_rank = True
+        #: orthonormalise the r head vectors (one Newton-Schulz step U <- U (1.5 I - 0.5 U^T U): an fp32 eigh leaves them
+        #: orthonormal to ~1e-6, afterwards to ~1e-12) before the head-form projector is built from them
         self.polish_basis = True
         #: dense projection on the low-precision matrix cores with fp32 accumulation and fp32-level error:
         #: "f16x2" (default) -- two fp16 terms per operand, three MFMAs per fp32-equivalent product, one power-of-two scale
@@ -95,7 +105,7 @@ class NSCLOptimizerBase(Optimizer):
             self._destroy_plans()
         self._plans, self._plan_key, self._workspaces, self._fast = [], None, [], None
         if not hasattr(self, "_basis"):
-            self._basis, self.low_rank, self.mutate_grad, self.polish_basis = {}, False, True, True
+            self._basis, self.low_rank, self.mutate_grad, self.polish_basis = {}, True, True, True
             self.eigh_batch = 16
             self.split_mfma, self._splits = SPLIT_MFMA_DEFAULT, {}
 
@@ -209,23 +219,34 @@ class NSCLOptimizerBase(Optimizer):
             self.set_basis(n, self.eigens[n]["eigen_vector"], first)
 
     def set_basis(self, name: str, V: torch.Tensor, rank: int, normalise=None):
-        """Install the projector of one parameter from an orthonormal eigenbasis: ``transforms[name] =
-        V[:, rank:] V[:, rank:]^T`` (Frobenius-normalised per the optimizer's rule) built by the HIP
-        SYRK kernel, and remember ``(V, rank)`` so that ``low_rank=True`` can apply it as
-        ``u - (u U) U^T``."""
+        """Install the projector of one parameter from an orthonormal eigenbasis ``V`` (columns in descending eigenvalue
+        order) whose first ``rank`` columns are removed: ``transforms[name] = V[:, rank:] V[:, rank:]^T``
+        (Frobenius-normalised per the optimizer's rule, SGD_NSCL.py:270-285).
+
+        With ``low_rank`` (default) and ``0 < rank <= LOW_RANK_MAX`` the SAME projector is built from the other side,
+        ``I - U U^T`` with ``U`` the orthonormalised ``V[:, :rank]`` (HIP kernel ``nsgp_build_projector_head``), and
+        ``U`` is remembered so that ``step`` can apply it as ``c (u - (u U) U^T)``; for an orthonormal ``V`` the two
+        constructions are the same matrix (an fp32 eigensolver's ``V`` is orthonormal to ~1e-6: the two differ by that
+        much, both sit at the same distance from the fp64 projector -- tests/test_gpu_parity.py).  Otherwise the HIP SYRK
+        kernel builds ``V_tail V_tail^T`` and the step runs the dense GEMM."""
         normalise = self._normalise(name) if normalise is None else normalise
-        if self.low_rank and self.polish_basis:
-            # V_tail V_tail^T == I - U U^T only for an orthonormal V; an fp32 eigh of a 4608-wide matrix is
-            # orthonormal to ~1e-5, which shows up as a 1e-5 difference between the two forms of the step.
-            # One Newton-Schulz step V <- V (1.5 I - 0.5 V^T V) squares that error (once per layer per task;
-            # two library GEMMs).  Both forms are then built from the SAME polished basis.
-            G = V.t() @ V
-            V = (1.5 * V - 0.5 * (V @ G)).contiguous()
-        P, norm = ops.build_projector(V, int(rank), normalise, return_norm=True)
+        D, rank = V.shape[0], int(rank)
+        if self.low_rank and 0 < rank <= LOW_RANK_MAX and D % 32 == 0:
+            U = V[:, :rank]
+            if self.polish_basis:       # on the r head columns only: an r x r Gram matrix, once per layer per task
+                U = 1.5 * U - 0.5 * (U @ (U.t() @ U))
+            rpad = (rank + 31) // 32 * 32
+            U_rm = torch.zeros(D, rpad, dtype=torch.float32, device=V.device)
+            U_rm[:, :rank] = U
+            U_kq = U_rm.view(D // 4, 4, rpad).permute(0, 2, 1).contiguous()     # k-quads [D/4][rpad][4]
+            P, norm = ops.build_projector_head(U_rm, normalise, return_norm=True)
+            # the caches hold the projector OBJECT (not its address: the allocator hands a freed [D x D] block straight
+            # to the next layer's projector) and compare identity + version
+            self._basis[name] = dict(U_rm=U_rm, U_kq=U_kq, rank=rank, norm=norm, c=None, P=P, P_version=P._version)
+        else:
+            P, norm = ops.build_projector(V, rank, normalise, return_norm=True)
+            self._basis.pop(name, None)
         self.transforms[name] = P.detach_()
-        # the caches hold the projector OBJECT (not its address: the allocator hands a freed [D x D] block straight to the
-        # next layer's projector) and compare identity + version
-        self._basis[name] = dict(V=V, rank=int(rank), norm=norm, P=P, P_version=P._version)
         self._splits.pop(name, None)
         self._plan_key = None  # new projector buffers -> new plan
         self._fast = None
@@ -296,16 +317,20 @@ class NSCLOptimizerBase(Optimizer):
                                            f"{tuple(P.shape)} {P.dtype} {P.device}")
                     d.proj = P.data_ptr()
                     d.rows, d.cols = rows, cols
-                    kind = _SPLIT_KINDS[self.split_mfma]
-                    if kind and rows % 128 == 0 and cols % 128 == 0:
-                        sp, sc = self._split_of(n, P, kind)
-                        d.proj_split, d.split_kind, d.split_scale = sp.data_ptr(), kind, sc
                     b = self._basis.get(n)
                     if (self.low_rank and b is not None and b["P"] is P and b["P_version"] == P._version
-                            and b["V"].is_contiguous()):
-                        d.basis = b["V"].data_ptr()          # only for projectors this optimizer built itself
+                            and rows % 32 == 0 and cols % 32 == 0):
+                        # only for head-form projectors this optimizer built itself and nobody touched since
+                        if b["c"] is None:
+                            b["c"] = 1.0 / float(b["norm"])
+                        d.basis, d.basis_rows = b["U_kq"].data_ptr(), b["U_rm"].data_ptr()
                         d.rank = int(b["rank"])
-                        d.basis_scale = 1.0 / float(b["norm"])
+                        d.basis_scale = b["c"]
+                    else:
+                        kind = _SPLIT_KINDS[self.split_mfma]
+                        if kind and rows % 128 == 0 and cols % 128 == 0:
+                            sp, sc = self._split_of(n, P, kind)
+                            d.proj_split, d.split_kind, d.split_scale = sp.data_ptr(), kind, sc
                 else:
                     d.proj = None
             nbytes = lib.nsgp_plan_workspace_bytes(descs, len(sub), self._kind)
@@ -354,7 +379,8 @@ class NSCLOptimizerBase(Optimizer):
         return tuple(tot)
 
     def lowrank_stats(self):
-        """(n_lowrank_layers, lowrank_flops, n_tiles_phase1, n_tiles_phase2) over the current plans."""
+        """(layers on the low-rank form, their FLOPs 4*Cout*D*r, workgroups of the T = u U launch, wave units of the apply
+        launch) over the current plans."""
         lib = _lib.load_library()
         tot = [0, 0.0, 0, 0]
         for plan in self._plans:

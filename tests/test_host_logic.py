@@ -28,14 +28,14 @@ def test_library_loads_and_exports_every_declared_symbol(N):
     assert declared == set(_lib.SIGNATURES), (declared ^ set(_lib.SIGNATURES))
     for name in declared:
         assert hasattr(lib, name), name
-    assert lib.nsgp_abi_version() == 6
+    assert lib.nsgp_abi_version() == 7
     assert lib.nsgp_device_count() >= 0
 
 
 def test_struct_layout_matches_header(N):
     import ctypes as C
     from nsgp_repre_amd import _lib
-    assert C.sizeof(_lib.TensorDesc) == 5 * 8 + 8 + 4 * 4 + 8 + 4 + 4 + 8 + 4 + 4      # + proj_split, split_scale (ABI 5)
+    assert C.sizeof(_lib.TensorDesc) == 5 * 8 + 8 + 4 * 4 + 8 + 4 + 4 + 8 + 4 + 4 + 8  # + proj_split, split_scale (ABI 5), basis_rows (ABI 7)
     assert C.sizeof(_lib.Hyper) == 16 * 4
 
 
