@@ -2,18 +2,22 @@
 
 One "step" = ONE TRAINING ITERATION of BASELINE.json configs[1] (Faster R-CNN R-50-FPN, VOC 15+5 task 2, 1 synthetic
 3x800x1344 image per GPU): teacher predict + pseudo-label filter, student forward (RPN + RoI losses + RePRE replay loss on the
-K=150 prototype bank), backward, SGDNSCL.step (50 projected layers: 118.3 GFLOP of projection, 0.584 GB of projectors)
-and zero_grad.  `value` = whole-job training img/s over all ranks (BASELINE's metric); `nsgp_step_ms` = the two HIP launches of
-the projected optimizer step inside that very loop (HIP events recorded by the library on the launch stream), and `roofline`
-is computed from the projection launch's average duration over the same K timed steps.
+K=150 prototype bank), backward, SGDNSCL.step (50 projected layers; the dense form is 118.3 GFLOP of projection against
+0.584 GB of projectors) and zero_grad.  The projectors come from SURVEY 8d's seeded covariances through the product's own
+get_eigens-style pipeline (eigh -> elbow -> set_basis), so the step runs the DEFAULT path: head-form projectors applied in the
+low-rank form p += c (u - (u U) U^T), which makes the step HBM-bound.  `value` = whole-job training img/s over all ranks
+(BASELINE's metric); `nsgp_step_ms` = the HIP launches of the projected optimizer step inside that very loop (HIP events recorded
+by the library on the launch stream); `roofline` is the step's dominant kernel (the multi-tensor update launch, HBM-bound) from
+its average duration over the same K timed steps, with the low-rank launches and the dense-GEMM kernel (still what externally
+assigned projectors run on) as blocks beside it.
 
 Multi-GPU: one process per GPU (torchrun); the detector is wrapped in DistributedDataParallel, so the bucketed RCCL all-reduce
 of the 41.5 M fp32 gradients (overlapped with backward) IS inside the timed region for N > 1; the projected step itself is
 replicated (identical gradients after the all-reduce, identical projectors) and has no exchange step of its own.
 
 Beside the headline the same JSON line carries, measured in the same process (rank 0, N = 1 only, never part of `value`):
-`hot_path` (the fork's additions alone -- SGDNSCL.step + replay loss on synthetic gradients, every MFMA path of the projection,
-the AdamW flavour, the opt-in low-rank form), `once_per_task` (covariance forward for R-50 and R-101, the 50-layer
+`hot_path` (the fork's additions alone -- SGDNSCL.step + replay loss on synthetic gradients: the default low-rank form, every
+MFMA path of the dense projection, the AdamW flavour), `once_per_task` (covariance forward for R-50 and R-101, the 50-layer
 get_eigens + get_transforms sweep, prototype-bank builds at three sizes, the R-101 step) and `cpu_baseline`.
 """
 import argparse
@@ -163,7 +167,8 @@ def once_per_task_units(N, dev):
              for n in names[:3]}
     out["eigens_and_transforms_r50"] = {
         "get_eigens_ms": (t1 - t0) * 1e3, "get_transforms_ms": (t2 - t1) * 1e3, "layers": len(layers),
-        "eigensolver": "torch.linalg.eigh (rocSOLVER syevd, a library call), equal-width layers batched 16 per call", "projector_kernel": "nsgp_projector_kernel (HIP SYRK)",
+        "eigensolver": "torch.linalg.eigh (rocSOLVER syevd, a library call), equal-width layers batched 16 per call",
+        "projector_kernel": "nsgp_projector_head_kernel (P = I - U U^T from the orthonormalised removed directions; HIP, fp32 MFMA)",
         "note": "the reference runs torch.svd on every rank, twice (runner:554-555); under DDP the product shards the layers over the ranks (runner/dist.py)",
         "example_ranks_removed": ranks}
     opt.close()
@@ -198,22 +203,25 @@ def once_per_task_units(N, dev):
     torch.cuda.synchronize()
     _, u_ms, g_ms = opt.profile_end()
     flops = opt.plan_stats()[0]
-    out["r101_projected_step"] = {"layers": len(layers), "elementwise_kernel_ms": u_ms, "projection_kernel_ms": g_ms, "nsgp_step_ms": u_ms + g_ms,
-                                  "algorithmic_flops": flops, "fp32_equivalent_tflops": flops / (g_ms * 1e-3) / 1e12, "path": opt.uses_split_mfma() or "f32"}
+    out["r101_projected_step"] = {"layers": len(layers), "elementwise_kernel_ms": u_ms, "projection_launches_ms": g_ms, "nsgp_step_ms": u_ms + g_ms,
+                                  "dense_form_flops": flops, "dense_equivalent_tflops": flops / (g_ms * 1e-3) / 1e12,
+                                  "layers_on_low_rank_form": opt.lowrank_stats()[0], "path": "low_rank (default)" if opt.lowrank_stats()[0] else (opt.uses_split_mfma() or "f32")}
     opt.close()
     return out
 
 
 def make_basis(D, dev, seed):
-    """A random orthonormal eigenbasis V [D x D]; the synthetic rank of the feature space is r = D//16,
-    so the projector is V[:, r:] V[:, r:]^T (built by the HIP SYRK kernel through set_basis)."""
+    """(V, first) for one layer width, the way a run produces them: C = X^T X with X = [4D x D] ~ N(0,1) *
+    diag(logspace(0,-3,D)) seeded, its eigenbasis by eigh on the GPU (descending), and the adaptive elbow index = the number
+    of removed directions (21 .. 91 for the R-50 / R-101 widths).  ``set_basis(name, V, first)`` then builds the projector."""
+    from nsgp_repre_amd.optim.threshold import elbow_index
     g = torch.Generator(device=dev).manual_seed(seed)
-    V = torch.eye(D, device=dev)
-    for _ in range(4):   # a product of 4 Householder reflections: dense, orthonormal to a few ulp, 8 launches
-        u = torch.randn(D, 1, device=dev, generator=g)
-        u = u / u.norm()
-        V = V - 2.0 * (V @ u) @ u.t()
-    return V.contiguous(), max(1, D // 16)
+    X = torch.randn(4 * D, D, device=dev, generator=g) * torch.logspace(0, -3, D, device=dev)[None, :]
+    lam, Q = torch.linalg.eigh((X.t() @ X).contiguous())
+    sv = lam.abs()
+    order = torch.argsort(sv, descending=True, stable=True)
+    first = int(elbow_index(sv[order].cpu().numpy(), 0.0, "sgd"))
+    return Q[:, order].contiguous(), max(1, first)
 
 
 def host_cores():
@@ -285,12 +293,53 @@ def _pmc_file():
     return None
 
 
-def roofline_block(split, flops, abytes_kernel, gemm_ms, update_ms, n_prof, numel, ntiles, nproj):
-    """`roofline` of the dominant kernel (the grouped projection GEMM).  The algorithm is an fp32 contraction of `flops`
-    (sum 2 Cout D^2 = 118.3 GFLOP per step for R-50-FPN -- one launch = one step's 50 layers).  `achieved` is ALGORITHMIC
-    FLOP/s = flops / the launch's average duration over the timed steps; `peak` is the dense peak of the matrix unit the kernel
-    runs on.  On the split paths every fp32 product is evaluated as three fp16 (six bf16) MFMA products, so the matrix cores
-    execute 3 x (6 x) that: reported beside it as `executed_mfma_utilisation`, never as `frac`."""
+def roofline_block(split, flops, abytes_kernel, gemm_ms, update_ms, n_prof, numel, ntiles, nproj, detail=None, lowrank=None,
+                   proj_numel=0, proj_bytes=0):
+    """`roofline` of the NSGP step's dominant kernel, from HIP events the library records around each launch of the timed steps.
+
+    DEFAULT path (every projected layer on the low-rank form; `lowrank` = the plan's low-rank stats): the step is three
+    HBM-bound launches.  The longest is the multi-tensor update (`nsgp_update_kernel`: g r, buf r+w, p r+w = 20 B per element over
+    all 41.2 M elements) -> `bound: hbm`, `achieved` = those algorithmic bytes / its average duration, `peak` 8 TB/s.  The
+    two low-rank launches are blocks beside it, each against the same HBM peak with ITS algorithmic bytes (T = u U reads the
+    update once: 4 B per projected element; apply reads the update and reads + writes p: 12 B per projected element), and
+    `dense_equivalent_tflops` says what rate a dense u @ P (sum 2 Cout D^2 = 118.3 GFLOP) would have needed to
+    finish in the time the low-rank launches take.
+
+    DENSE path (projectors assigned from outside, or low_rank = False): the grouped projection GEMM dominates -> `bound: mfma`,
+    `achieved` = ALGORITHMIC FLOP/s = flops / the launch's average duration, `peak` = the dense peak of the matrix unit the kernel
+    runs on; on the split paths every fp32 product is evaluated as three fp16 (six bf16) MFMA products, reported as
+    `executed_mfma_utilisation`, never as `frac`."""
+    update_bytes = 5 * 4 * numel
+    upd = {"kernel": "nsgp_update_kernel<SGD> (multi-tensor elementwise update: weight decay, momentum, p += update for un-projected tensors)",
+           "bound": "hbm", "achieved": update_bytes / (update_ms * 1e-3) / 1e9, "peak": PEAK_HBM_GBS, "unit": "GB/s",
+           "kernel_ms": update_ms, "algorithmic_bytes": update_bytes,
+           "algorithmic_bytes_note": "g r, buf r+w, p r+w = 20 B per element over every listed tensor (41.2 M elements)"}
+    upd["frac"] = upd["achieved"] / PEAK_HBM_GBS
+    f = _pmc_file()
+    tr = json.load(open(f)) if f else {}
+    if lowrank and lowrank[0] == nproj and detail:
+        dense_ms, t_ms, apply_ms = detail
+        out = dict(upd)
+        out.update({"profiled_steps": n_prof, "layers": nproj, "traffic": tr.get("nsgp_update_kernel_hbm_bytes_per_launch"),
+                    "traffic_source": tr.get("source"),
+                    "nsgp_step_launches": "nsgp_update_kernel -> nsgp_lr_t_kernel (+ nsgp_lr_reduce_kernel) -> nsgp_lr_apply_kernel",
+                    "lowrank_t": {"kernel": "nsgp_lr_t_kernel<SGD> + nsgp_lr_reduce_kernel (T = u U, exact fp32 MFMA, K slices summed in order)",
+                                  "bound": "hbm", "kernel_ms": t_ms, "algorithmic_bytes": 4 * proj_numel,
+                                  "achieved": 4 * proj_numel / (t_ms * 1e-3) / 1e9, "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                                  "frac": 4 * proj_numel / (t_ms * 1e-3) / 1e9 / PEAK_HBM_GBS,
+                                  "mfma_flops": lowrank[1] / 2, "mfma_tflops": lowrank[1] / 2 / (t_ms * 1e-3) / 1e12,
+                                  "mfma_frac_of_fp32_matrix_peak": lowrank[1] / 2 / (t_ms * 1e-3) / 1e12 / PEAK_FP32_MATRIX_TFLOPS,
+                                  "note": "reads the update once (4 B per projected element); 2*Cout*D*r FLOP on v_mfma_f32_32x32x2_f32"},
+                    "lowrank_apply": {"kernel": "nsgp_lr_apply_kernel<SGD> (p += c (u - T U^T), exact fp32 MFMA, K = r)",
+                                      "bound": "hbm", "kernel_ms": apply_ms, "algorithmic_bytes": 12 * proj_numel,
+                                      "achieved": 12 * proj_numel / (apply_ms * 1e-3) / 1e9, "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                                      "frac": 12 * proj_numel / (apply_ms * 1e-3) / 1e9 / PEAK_HBM_GBS,
+                                      "note": "reads the update, reads and writes p (12 B per projected element)"},
+                    "lowrank_flops": lowrank[1], "dense_form_flops": flops,
+                    "dense_equivalent_tflops": flops / ((t_ms + apply_ms) * 1e-3) / 1e12,
+                    "dense_equivalent_note": "the rate a dense u @ P over the same layers (SURVEY 8d's 118.3 GFLOP) would need to match the low-rank "
+                                             "launches; the dense fp16-split kernel itself is timed under hot_path.mfma_paths / roofline_dense_f16x2"})
+        return out
     alg_tf = flops / (gemm_ms * 1e-3) / 1e12
     mult = {"bf16x3": 6, "f16x2": 3}.get(split, 1)
     peak = PEAK_16BIT_MATRIX_TFLOPS if split else PEAK_FP32_MATRIX_TFLOPS
@@ -305,14 +354,11 @@ def roofline_block(split, flops, abytes_kernel, gemm_ms, update_ms, n_prof, nume
            "elementwise_kernel_ms": update_ms, "elementwise_kernel_hbm_gbs": (5 * 4 * numel) / (update_ms * 1e-3) / 1e9,
            "elementwise_note": "nsgp_update_kernel: g r, buf r+w, p r+w = 20 B/element algorithmic (+4 B/element of split copy for projected tensors on the fp16 path)",
            "traffic": None}
-    f = _pmc_file()
-    if f:   # HBM bytes per launch + MFMA-busy from the rocprofv3 --pmc passes of this same command (tools/profile.sh)
-        tr = json.load(open(f))
-        if split == "f16x2" or "kernel" not in tr:
-            out["traffic"] = tr.get("nsgp_project_kernel_hbm_bytes_per_launch")
-            out["traffic_source"] = tr.get("source")
-            if "mfma_busy_fraction" in tr:
-                out["mfma_busy_fraction_pmc"] = tr["mfma_busy_fraction"]
+    if tr and (split == "f16x2" or "kernel" not in tr):   # HBM bytes per launch + MFMA-busy from the rocprofv3 --pmc passes (tools/profile.sh)
+        out["traffic"] = tr.get("nsgp_project_kernel_hbm_bytes_per_launch")
+        out["traffic_source"] = tr.get("source")
+        if "mfma_busy_fraction" in tr:
+            out["mfma_busy_fraction_pmc"] = tr["mfma_busy_fraction"]
     return out
 
 
@@ -391,6 +437,7 @@ def end_to_end_training(N, dev, world, local_rank, basis_cache, steps, warmup, a
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = t.item()
     n_prof, update_ms, gemm_ms = opt.profile_end()
+    detail, lowrank = opt.profile_detail(), opt.lowrank_stats()
     flops, _abytes, ntiles, nproj = opt.plan_stats()
     split = opt.uses_split_mfma()
     proj_numel = sum(p.numel() for g_ in opt.param_groups for n_, p in zip(g_["names"], g_["params"]) if n_ in opt.transforms)
@@ -406,7 +453,10 @@ def end_to_end_training(N, dev, world, local_rank, basis_cache, steps, warmup, a
            "teacher_student_fwd_bwd_ms": sum(fwd_bwd) / len(fwd_bwd), "optimizer_step_ms": sum(opt_ms) / len(opt_ms),
            "nsgp_kernels_ms": update_ms + gemm_ms, "projected_layers": n_proj,
            "_roofline": dict(split=split, flops=flops, abytes_kernel=proj_bytes + 3 * 4 * proj_numel, gemm_ms=gemm_ms, update_ms=update_ms,
-                             n_prof=n_prof, numel=all_numel, ntiles=ntiles, nproj=nproj),
+                             n_prof=n_prof, numel=all_numel, ntiles=ntiles, nproj=nproj, detail=detail, lowrank=lowrank,
+                             proj_numel=proj_numel, proj_bytes=proj_bytes),
+           "nsgp_update_kernel_ms": update_ms, "nsgp_lowrank_t_ms": detail[1], "nsgp_lowrank_apply_ms": detail[2], "nsgp_dense_gemm_ms": detail[0],
+           "layers_on_low_rank_form": lowrank[0],
            "trainable_tensors": sum(len(g["params"]) for g in opt.param_groups),
            "losses_finite": finite, "loss_keys": sorted(losses.keys()),
            "detector_dtype": "bf16 autocast (replay-bank pass, losses, NSGP step fp32)" if amp else "f32",
@@ -483,39 +533,55 @@ def hot_path_only(N, dev, args, cache):
         return ms, u_ms, g_ms
 
     flops = None
-    out = {"workload": "SGDNSCL.step over 50 projected layers + 112 plain tensors (41.2M params) + replay loss fwd/bwd on K=150 prototypes; synthetic gradients",
+    out = {"workload": "SGDNSCL.step over 50 projected layers + 112 plain tensors (41.2M params) + replay loss fwd/bwd on K=150 prototypes; synthetic gradients; "
+                       "projectors from SURVEY 8d's seeded covariances (eigh -> elbow -> set_basis)",
            "mfma_paths": {}}
+    proj_numel = sum(int(torch.tensor(shape).prod()) for _, shape, proj in table if proj)
+    # ---- the DEFAULT path: head-form projectors applied in the low-rank form (north_star: g - U (U^T g))
+    assert opt.low_rank is True
+    ms, u_ms, g_ms = timed(args.steps)
+    out["host_ms_in_optimizer_step"] = 1e3 * sum(host_step[-args.steps:]) / max(1, len(host_step[-args.steps:]))
+    n_lr, lr_flops, lt1, lt2 = opt.lowrank_stats()
+    dense_ms, t_ms, a_ms = opt.profile_detail()
+    flops = opt.plan_stats()[0]
+    out["low_rank_form"] = {
+        "default": True, "ms_per_step": ms, "nsgp_step_ms": u_ms + g_ms, "elementwise_kernel_ms": u_ms, "lowrank_t_ms": t_ms, "lowrank_apply_ms": a_ms,
+        "projection_launches_ms": g_ms, "layers": n_lr, "removed_directions_per_width": {str(D): int(v[1]) for D, v in sorted(cache.items())},
+        "lowrank_flops": lr_flops, "dense_form_flops": flops, "dense_equivalent_tflops": flops / (g_ms * 1e-3) / 1e12,
+        "elementwise_hbm_gbs": 5 * 4 * flat_numel_real / (u_ms * 1e-3) / 1e9,
+        "lowrank_t_hbm_gbs": 4 * proj_numel / (t_ms * 1e-3) / 1e9 if t_ms else None,
+        "lowrank_apply_hbm_gbs": 12 * proj_numel / (a_ms * 1e-3) / 1e9 if a_ms else None,
+        "workgroups": {"lowrank_t": lt1, "lowrank_apply": lt2},
+        "note": "parity: tests/test_gpu_parity.py::test_full_table_low_rank_default_vs_oracle_per_row, ::test_low_rank_form_matches_dense_form, ::test_g1b_default_pipeline_from_covariance_per_row"}
+    # ---- the dense GEMM on every MFMA path, with the SAME projectors (what externally assigned projectors run on)
+    opt.low_rank = False
     for path in ("f16x2", "bf16x3", False):
         opt.split_mfma = path
         ms, u_ms, g_ms = timed(args.steps)
-        if path == "f16x2":     # host time of step() on the default path (on the slower paths the host catches up with the 4-deep upload ring and waits)
-            out["host_ms_in_optimizer_step"] = 1e3 * sum(host_step[-args.steps:]) / max(1, len(host_step[-args.steps:]))
-        flops = opt.plan_stats()[0]
         tf = flops / (g_ms * 1e-3) / 1e12
+        if path == "f16x2":
+            v2_tiles = opt.tile_counts()[2]
         out["mfma_paths"][path or "f32"] = {
             "uses_split_mfma": opt.uses_split_mfma(), "ms_per_step": ms, "nsgp_step_ms": u_ms + g_ms, "elementwise_kernel_ms": u_ms,
             "projection_kernel_ms": g_ms, "fp32_equivalent_tflops": tf,
             "frac_of_unit_peak": tf / (PEAK_16BIT_MATRIX_TFLOPS if path else PEAK_FP32_MATRIX_TFLOPS),
             "frac_of_fp32_matrix_peak": tf / PEAK_FP32_MATRIX_TFLOPS}
-    f32 = out["mfma_paths"]["f32"]
+    f32, f16 = out["mfma_paths"]["f32"], out["mfma_paths"]["f16x2"]
     out["roofline_fp32_mfma"] = {"bound": "mfma", "kernel": "nsgp_project_kernel<SGD,fast> (v_mfma_f32_32x32x2_f32, exact fp32)",
                                  "achieved": f32["fp32_equivalent_tflops"], "peak": PEAK_FP32_MATRIX_TFLOPS, "unit": "TFLOP/s",
                                  "frac": f32["frac_of_fp32_matrix_peak"], "kernel_ms": f32["projection_kernel_ms"]}
+    pbytes = sum(P.numel() * 4 for P in opt.transforms.values())
+    out["roofline_dense_f16x2"] = roofline_block("f16x2", flops, pbytes + 3 * 4 * proj_numel, f16["projection_kernel_ms"], f16["elementwise_kernel_ms"],
+                                                 args.steps, flat_numel_real, v2_tiles, n_lr)
     opt.split_mfma = "f16x2"
-    # opt-in low-rank form of the same projectors (north_star: g - U(U^T g))
     opt.low_rank = True
-    ms, u_ms, g_ms = timed(args.steps)
-    n_lr, lr_flops, lt1, lt2 = opt.lowrank_stats()
-    out["lowrank_form"] = {"ms_per_step": ms, "nsgp_step_ms": u_ms + g_ms, "projection_launches_ms": g_ms, "layers": n_lr,
-                           "algorithmic_flops": lr_flops, "achieved_tflops": lr_flops / (g_ms * 1e-3) / 1e12, "synthetic_rank": "r = D/16",
-                           "note": "opt-in (optimizer.low_rank=True); parity vs the dense form: tests/test_gpu_parity.py::test_low_rank_form_matches_dense_form"}
-    opt.low_rank = False
     # the AdamW flavour of the same step (schedule_1x_adamwnscl.py:21) -- row a3 of SURVEY 8; parity: the G1 / G1b adamw goldens
     adamw = N.AdamWNSCL(params, lr=1e-4, weight_decay=0.1, svd=True)
     adamw.param_groups[0]["names"] = names
     for n, shape, proj in table:
         if proj:
-            adamw.transforms[n] = opt.transforms[n]
+            D = shape[1] * shape[2] * shape[3]
+            adamw.set_basis(n, cache[D][0], cache[D][1])
     flat_grads.copy_(synth_flat)
     for _ in range(3):
         adamw.step()
@@ -525,10 +591,10 @@ def hot_path_only(N, dev, args, cache):
         adamw.step()
     torch.cuda.synchronize()
     _, aw_u, aw_g = adamw.profile_end()
-    out["adamw_nscl"] = {"nsgp_step_ms": aw_u + aw_g, "elementwise_kernel_ms": aw_u, "projection_kernel_ms": aw_g,
-                         "fp32_equivalent_tflops": flops / (aw_g * 1e-3) / 1e12,
-                         "elementwise_hbm_gbs": 7 * 4 * flat_numel_real / (aw_u * 1e-3) / 1e9,
-                         "note": "AdamWNSCL.step, same table; elementwise bytes: g r, m r+w, v r+w, p r+w"}
+    out["adamw_nscl"] = {"nsgp_step_ms": aw_u + aw_g, "elementwise_kernel_ms": aw_u, "projection_launches_ms": aw_g,
+                         "layers_on_low_rank_form": adamw.lowrank_stats()[0],
+                         "elementwise_hbm_gbs": 8 * 4 * flat_numel_real / (aw_u * 1e-3) / 1e9,
+                         "note": "AdamWNSCL.step, same table, default (low-rank) path; elementwise bytes: g r, m r+w, v r+w, p r (+ u w for projected tensors)"}
     adamw.close()
     opt.close()
     return out, table
@@ -580,8 +646,8 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": e2e["ms_per_step"],
             "nsgp_step_ms": rf["update_ms"] + rf["gemm_ms"],
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32 (NSGP step: parameters, gradients, state, accumulation; the projection's products as two-term fp16 splits on the "
-                     "matrix cores)" + ("" if args.f32_detector else "; detector forward/backward under bf16 autocast"),
+            "dtype": "f32 (NSGP step: parameters, gradients, state and every product -- the low-rank form runs on the exact fp32 MFMA)"
+                     + ("" if args.f32_detector else "; detector forward/backward under bf16 autocast"),
             "data": "synthetic",
             "config": {"workload": "R-50-FPN VOC 15+5 task 2 (configs[1]), 1 synthetic 3x800x1344 image per GPU per step, 50 projected layers, K=150 prototype bank",
                        "global_batch": world * args.batch_per_gpu, "parallelism": f"ddp{world}" if world > 1 else "single"},

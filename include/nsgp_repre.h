@@ -78,7 +78,7 @@ typedef struct {
     int32_t cols;       /* D     = numel / rows = Cin*kh*kw  (projected tensors only) */
     int32_t hyper;      /* index into the per-step hyper array */
     int32_t rank;       /* low-rank form (optional): number of REMOVED directions r (the top eigenvectors = first_col of the projector) */
-    const float* basis; /* low-rank form (optional, ABI 7): U as k-quads [cols/4][rpad][4] fp32, rpad = rank rounded up to 32,
+    const float* basis; /* low-rank form (optional, ABI 7): U as k-quads [cols/4][rpad][4] fp32, rpad = 32 / 64 / 128 (the smallest >= rank),
                            columns >= rank zero (element (k, j) at ((k/4)*rpad + j)*4 + k%4).  With `basis_rows` non-NULL,
                            0 < rank <= 128, rows % 32 == 0 and cols % 32 == 0 the step applies
                            p += basis_scale * (u - (u U) U^T)      (the north star's g - U (U^T g))
@@ -153,10 +153,13 @@ int nsgp_plan_uses_split_mfma(const nsgp_plan_t* plan);
 int nsgp_plan_tile_counts(const nsgp_plan_t* plan, int* fast_128, int* generic_128, int* split_f16_256);
 
 /* Per-launch timing with HIP events recorded on the launch stream (measurement only): between
- * _begin and _end each nsgp_plan_step records 3 events; _end synchronises on them and returns
- * the average duration of the elementwise launch and of the projection-GEMM launch(es). */
+ * _begin and _end each nsgp_plan_step records 5 events; _end synchronises on them and returns
+ * the average duration of the elementwise launch and of the projection launches (dense GEMM and / or low-rank) together. */
 int nsgp_plan_profile_begin(nsgp_plan_t* plan, int max_steps);
 int nsgp_plan_profile_end(nsgp_plan_t* plan, int* n_steps, float* update_ms_avg, float* gemm_ms_avg);
+/* The projection part of the last _end, launch by launch (ABI 7): the dense GEMM launch(es), the low-rank T = u U launch
+ * (+ its slab reduce), the low-rank apply launch; averages in ms over the profiled steps, 0 for launches a plan does not make. */
+int nsgp_plan_profile_detail(const nsgp_plan_t* plan, float* dense_ms, float* lowrank_t_ms, float* lowrank_apply_ms);
 
 /* Three-term bf16 split of the TRANSPOSE of a projector (proj = sum of the three terms to 24 mantissa bits), in the layout
  * the split-MFMA projection kernel streams: [n][k/8][term][8] bf16, 6 bytes per element.  Once per projector per task.

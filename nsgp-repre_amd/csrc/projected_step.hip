@@ -85,6 +85,7 @@ struct ChunkDev {
 
 constexpr int CHUNK = 16384;  // elements per workgroup of the elementwise kernel
 constexpr int NSLOT = 4;      // depth of the per-step upload ring
+constexpr int PROF_EV = 5;    // events per profiled step
 
 struct DynBlock {  // uploaded every step: hyper sets + current grad pointers
     nsgp_hyper_t hyper[NSGP_MAX_HYPER];
@@ -407,9 +408,9 @@ __global__ __launch_bounds__(256, 2) void nsgp_project_single_kernel(const float
 // FLOP and NO projector traffic instead of 2*Cout*D^2 FLOP and D^2 projector bytes -- the step becomes HBM-bound on the
 // update itself.  Everything is exact fp32 on v_mfma_f32_32x32x2_f32 (lane l supplies A[i = l & 31][k'] and
 // B[k'][j = l & 31], k' = l >> 5): at r <= 128 the matrix work is a few GFLOP per step and hides under the memory stream.
-// Both launches serve every rank class (rpad = 32 .. 128) of a plan at once.
+// Both launches serve every rank class (U padded to rpad = 32, 64 or 128 columns) of a plan at once.
 //
-//   launch T  (nsgp_lr_t_kernel):      T[32 rows x rpad] = scale * (S U).  One workgroup of 12 waves per (32-row block,
+//   launch T  (nsgp_lr_t_kernel):      T[32 rows x rpad] = scale * (S U).  One workgroup of 8 waves per (32-row block,
 //             K range s of the layer's S): wave w takes the 32-column block jb = w % NJ of U (NJ = rpad / 32) and the
 //             K slice w / NJ of the range, so a wave holds ONE 32 x 32 accumulator whatever the rank.  Each lane loads
 //             16 B of its row per k8 step straight into the MFMA's A register (k = 8t + 4h + e on step e: ANY assignment
@@ -436,8 +437,9 @@ __device__ __forceinline__ void lowrank_source(const LayerDev& L, const DynBlock
     }
 }
 
-constexpr int LRT_WAVES = 12;        // divisible by every NJ = 1 .. 4
+constexpr int LRT_WAVES = 8;         // divisible by NJ = rpad / 32 in {1, 2, 4}; two workgroups per CU (114 VGPRs, 37 KB of LDS)
 constexpr int LRA_COLS = 256;        // columns of one apply workgroup
+static_assert(LRA_COLS == 256, "the apply kernel gives each of its four waves at most two 32-column blocks");
 constexpr int LR_MAX_RANK = 128;
 constexpr int LR_TILE_LD = 36;       // floats per row of a [32 x 32] LDS tile: 144 B, so that 8 lanes reading 16 B of 8 consecutive rows cover all 32 banks
 constexpr int LR_TILE = 32 * LR_TILE_LD;
@@ -459,7 +461,7 @@ __device__ __forceinline__ f32x4 lds_get4(const float* tile, int off) { return *
 template <int OPT>
 __global__ __launch_bounds__(LRT_WAVES * 64) void nsgp_lr_t_kernel(const TileDev* __restrict__ units, const LayerDev* __restrict__ layers,
                                                                   const DynBlock* __restrict__ dyn) {
-    __shared__ __attribute__((aligned(16))) float lds[LRT_WAVES * LR_TILE];   // the waves' A tiles; afterwards the 12 partial T blocks (1024 floats each)
+    __shared__ __attribute__((aligned(16))) float lds[LRT_WAVES * LR_TILE];   // the waves' A tiles; afterwards the waves' partial T blocks (1024 floats each)
     const TileDev t = units[blockIdx.x];           // m0 = first row, pad = K range index s
     const LayerDev L = layers[t.layer];
     const float* A;
@@ -514,7 +516,7 @@ __global__ __launch_bounds__(LRT_WAVES * 64) void nsgp_lr_t_kernel(const TileDev
         if (g + 1 < g1) mma(IC<1>{});
     }
     // the K slices of each column block, summed in slice order (deterministic)
-    __syncthreads();                               // every wave is done with its A tile: the buffer becomes the 12 partial blocks
+    __syncthreads();                               // every wave is done with its A tile: the buffer becomes the partial blocks
     float* mine = lds + wave * 1024;
 #pragma unroll
     for (int v = 0; v < 16; ++v) mine[acc_row(v, lane) * 32 + i] = acc[v];
@@ -562,24 +564,30 @@ __global__ __launch_bounds__(256) void nsgp_lr_apply_kernel(const TileDev* __res
     const int i = lane & 31, h = lane >> 5, r8 = lane >> 3, ch = lane & 7;
     const float c = L.basis_scale;
     const int NJ = L.rpad >> 5, tld = L.rpad + 4;
+    // The MFMA computes the TRANSPOSED block C[n][m] = sum_k U[n][k] T[m][k] (A operand = U rows, B operand = T rows): lane
+    // (i, h) then holds, for row m = m0 + i, the columns n + 8 g + 4 h + (0..3), g = 0..3 -- four 16-byte pieces for the tile.
+    // The four waves take ADJACENT 32-column blocks (512 contiguous bytes per row at a time), then the next 128 columns
+    // (at most two blocks per wave).  The S / p loads of a wave's first block are issued BEFORE the T tile is staged and those of
+    // its second block before the first is computed: the HBM latency of the stream never sits behind an LDS stage or the MFMAs.
+    const long r8s = 8L * L.cols;
+    const long off0 = (long)(t.m0 + r8) * L.cols + t.n0 + 32 * wave + 4 * ch;
+    const bool has0 = 32 * wave < t.pad, has1 = 32 * wave + 128 < t.pad;
+    f32x4 av0[4], pv0[4], av1[4], pv1[4];
+    if (has0) {
+#pragma unroll
+        for (int it = 0; it < 4; ++it) { av0[it] = load4_a4(A + off0 + it * r8s); pv0[it] = *(const gf32x4*)(L.p + off0 + it * r8s); }
+    }
     for (int x = threadIdx.x; x < 8 * L.rpad; x += 256) {                               // 32 rows x rpad / 4 pieces, contiguous in memory
         const int row = x / (L.rpad >> 2), c4 = x - row * (L.rpad >> 2);
         lds_put4(t_lds, row * tld + 4 * c4, *(const gf32x4*)(L.T + (long)t.m0 * L.rpad + 4L * x));
     }
+    if (has1) {
+#pragma unroll
+        for (int it = 0; it < 4; ++it) { av1[it] = load4_a4(A + off0 + 128 + it * r8s); pv1[it] = *(const gf32x4*)(L.p + off0 + 128 + it * r8s); }
+    }
     __syncthreads();
     float* tile = w_lds + wave * LR_TILE;
-    // The MFMA computes the TRANSPOSED block C[n][m] = sum_k U[n][k] T[m][k] (A operand = U rows, B operand = T rows): lane
-    // (i, h) then holds, for row m = m0 + i, the columns n + 8 g + 4 h + (0..3), g = 0..3 -- four 16-byte pieces for the tile.
-    // The four waves take ADJACENT 32-column blocks (512 contiguous bytes per row at a time), then the next 128 columns.
-    for (int n = t.n0 + 32 * wave; n < t.n0 + t.pad; n += 128) {
-        const long off = (long)(t.m0 + r8) * L.cols + n + 4 * ch;
-        const long r8s = 8L * L.cols;
-        f32x4 av[4], pv[4];
-#pragma unroll
-        for (int it = 0; it < 4; ++it) {
-            av[it] = load4_a4(A + off + it * r8s);
-            pv[it] = *(const gf32x4*)(L.p + off + it * r8s);
-        }
+    auto block = [&](int n, long off, const f32x4 (&av)[4], const f32x4 (&pv)[4]) {
         f32x16 acc;
 #pragma unroll
         for (int v = 0; v < 16; ++v) acc[v] = 0.0f;
@@ -611,7 +619,9 @@ __global__ __launch_bounds__(256) void nsgp_lr_apply_kernel(const TileDev* __res
             for (int e = 0; e < 4; ++e) o[e] = pv[it][e] + c * (scale * av[it][e] - cv[e]);
             *(gf32x4*)(L.p + off + it * r8s) = o;
         }
-    }
+    };
+    if (has0) block(t.n0 + 32 * wave, off0, av0, pv0);
+    if (has1) block(t.n0 + 32 * wave + 128, off0 + 128, av1, pv1);
 }
 
 // ---- host: plan ---------------------------------------------------------------
@@ -655,9 +665,11 @@ struct nsgp_plan {
     hipEvent_t ev[NSLOT] = {nullptr, nullptr, nullptr, nullptr};
     bool ev_used[NSLOT] = {false, false, false, false};
     int slot = 0;
-    // optional per-launch timing: 3 events per recorded step (before update, between, after GEMM)
+    // optional per-launch timing: PROF_EV events per recorded step (before the update launch, after it, after the dense GEMM
+    // launches, after the low-rank T (+ reduce) launches, after the low-rank apply launch)
     std::vector<hipEvent_t> prof_ev;
     int prof_cap = 0, prof_n = 0;
+    float prof_detail[3] = {0, 0, 0};   // averages of the last profile_end: dense GEMM, low-rank T (+ reduce), low-rank apply
 };
 
 static bool tensor_fast(const nsgp_tensor_t& t) {
@@ -675,7 +687,7 @@ static bool tensor_lowrank(const nsgp_tensor_t& t) {
     return t.basis && t.basis_rows && t.rank > 0 && t.rank <= LR_MAX_RANK && t.rows % 32 == 0 && t.cols % 32 == 0 &&
            aligned16(t.basis) && aligned16(t.basis_rows) && t.proj;
 }
-static int lr_rpad(int rank) { return (rank + 31) / 32 * 32; }
+static int lr_rpad(int rank) { return rank <= 32 ? 32 : (rank <= 64 ? 64 : 128); }   // U's padded width: 32, 64 or 128 columns
 // K ranges of a low-rank layer's T launch: a workgroup's MFMA time is (D/8 k8-steps) x 4 MFMAs x 64 clk x NJ column blocks
 // over 4 SIMDs = D * NJ * 8 clk; keep it under ~12,000 clk (5 us)
 static int lr_nsplit(int cols, int rank) {
@@ -1035,14 +1047,14 @@ extern "C" int nsgp_plan_step(nsgp_plan_t* P, float* const* grads, const nsgp_hy
     NSGP_HIP(hipMemcpyAsync(P->d_dyn[s], P->h_dyn[s], P->dyn_bytes, hipMemcpyHostToDevice, stream));
     const DynBlock* d = reinterpret_cast<const DynBlock*>(P->d_dyn[s]);
     const bool prof = P->prof_n < P->prof_cap;
-    if (prof) NSGP_HIP(hipEventRecord(P->prof_ev[3 * P->prof_n + 0], stream));
+    if (prof) NSGP_HIP(hipEventRecord(P->prof_ev[PROF_EV * P->prof_n + 0], stream));
 
     if (P->optimizer == NSGP_OPT_SGD)
         hipLaunchKernelGGL(nsgp_update_kernel<NSGP_OPT_SGD>, dim3(P->n_chunks), dim3(256), 0, stream, P->d_chunks, P->d_tensors, d);
     else
         hipLaunchKernelGGL(nsgp_update_kernel<NSGP_OPT_ADAM>, dim3(P->n_chunks), dim3(256), 0, stream, P->d_chunks, P->d_tensors, d);
     NSGP_LAUNCH_CHECK();
-    if (prof) NSGP_HIP(hipEventRecord(P->prof_ev[3 * P->prof_n + 1], stream));
+    if (prof) NSGP_HIP(hipEventRecord(P->prof_ev[PROF_EV * P->prof_n + 1], stream));
     if (P->n_tiles_v2 > 0) {
         const TileDev* vt = P->d_tiles + P->n_tiles_fast + P->n_tiles_generic + P->n_tiles_lr1 + P->n_tiles_lr2;
         if (P->optimizer == NSGP_OPT_SGD)
@@ -1071,6 +1083,7 @@ extern "C" int nsgp_plan_step(nsgp_plan_t* P, float* const* grads, const nsgp_hy
             hipLaunchKernelGGL((nsgp_project_kernel<NSGP_OPT_ADAM, false>), dim3(P->n_tiles_generic), dim3(THREADS), SMEM_BYTES, stream, gt, P->d_layers, d);
         NSGP_LAUNCH_CHECK();
     }
+    if (prof) NSGP_HIP(hipEventRecord(P->prof_ev[PROF_EV * P->prof_n + 2], stream));
     if (P->n_tiles_lr1 > 0) {
         const TileDev* t1 = P->d_tiles + P->n_tiles_fast + P->n_tiles_generic;
         const TileDev* t2 = t1 + P->n_tiles_lr1;
@@ -1083,6 +1096,7 @@ extern "C" int nsgp_plan_step(nsgp_plan_t* P, float* const* grads, const nsgp_hy
             hipLaunchKernelGGL(nsgp_lr_reduce_kernel, dim3(P->n_chunks_lr), dim3(256), 0, stream, P->d_chunks_lr, P->d_layers, d, P->optimizer);
             NSGP_LAUNCH_CHECK();
         }
+        if (prof) NSGP_HIP(hipEventRecord(P->prof_ev[PROF_EV * P->prof_n + 3], stream));
         if (P->optimizer == NSGP_OPT_SGD)
             hipLaunchKernelGGL(nsgp_lr_apply_kernel<NSGP_OPT_SGD>, dim3(P->n_tiles_lr2), dim3(256), 0, stream, t2, P->d_layers, d);
         else
@@ -1090,7 +1104,8 @@ extern "C" int nsgp_plan_step(nsgp_plan_t* P, float* const* grads, const nsgp_hy
         NSGP_LAUNCH_CHECK();
     }
     if (prof) {
-        NSGP_HIP(hipEventRecord(P->prof_ev[3 * P->prof_n + 2], stream));
+        if (P->n_tiles_lr1 == 0) NSGP_HIP(hipEventRecord(P->prof_ev[PROF_EV * P->prof_n + 3], stream));
+        NSGP_HIP(hipEventRecord(P->prof_ev[PROF_EV * P->prof_n + 4], stream));
         ++P->prof_n;
     }
     NSGP_HIP(hipEventRecord(P->ev[s], stream));
@@ -1100,7 +1115,7 @@ extern "C" int nsgp_plan_step(nsgp_plan_t* P, float* const* grads, const nsgp_hy
 
 extern "C" int nsgp_plan_profile_begin(nsgp_plan_t* P, int max_steps) {
     if (!P || max_steps < 0 || max_steps > 4096) return fail(NSGP_ERR_INVALID, "nsgp_plan_profile_begin: bad argument");
-    while ((int)P->prof_ev.size() < 3 * max_steps) {
+    while ((int)P->prof_ev.size() < PROF_EV * max_steps) {
         hipEvent_t e;
         NSGP_HIP(hipEventCreate(&e));
         P->prof_ev.push_back(e);
@@ -1112,20 +1127,32 @@ extern "C" int nsgp_plan_profile_begin(nsgp_plan_t* P, int max_steps) {
 
 extern "C" int nsgp_plan_profile_end(nsgp_plan_t* P, int* n_steps, float* update_ms_avg, float* gemm_ms_avg) {
     if (!P) return fail(NSGP_ERR_INVALID, "nsgp_plan_profile_end: null plan");
-    double u = 0, g = 0;
+    double u = 0, g = 0, det[3] = {0, 0, 0};
     for (int i = 0; i < P->prof_n; ++i) {
-        NSGP_HIP(hipEventSynchronize(P->prof_ev[3 * i + 2]));
-        float a = 0, b = 0;
-        NSGP_HIP(hipEventElapsedTime(&a, P->prof_ev[3 * i + 0], P->prof_ev[3 * i + 1]));
-        NSGP_HIP(hipEventElapsedTime(&b, P->prof_ev[3 * i + 1], P->prof_ev[3 * i + 2]));
+        hipEvent_t* e = &P->prof_ev[PROF_EV * i];
+        NSGP_HIP(hipEventSynchronize(e[4]));
+        float a = 0, b = 0, d3[3] = {0, 0, 0};
+        NSGP_HIP(hipEventElapsedTime(&a, e[0], e[1]));
+        NSGP_HIP(hipEventElapsedTime(&b, e[1], e[4]));
+        for (int k = 0; k < 3; ++k) NSGP_HIP(hipEventElapsedTime(&d3[k], e[1 + k], e[2 + k]));
         u += a;
         g += b;
+        for (int k = 0; k < 3; ++k) det[k] += d3[k];
     }
+    for (int k = 0; k < 3; ++k) P->prof_detail[k] = P->prof_n ? (float)(det[k] / P->prof_n) : 0.0f;
     if (n_steps) *n_steps = P->prof_n;
     if (update_ms_avg) *update_ms_avg = P->prof_n ? (float)(u / P->prof_n) : 0.0f;
     if (gemm_ms_avg) *gemm_ms_avg = P->prof_n ? (float)(g / P->prof_n) : 0.0f;
     P->prof_cap = 0;
     P->prof_n = 0;
+    return NSGP_OK;
+}
+
+extern "C" int nsgp_plan_profile_detail(const nsgp_plan_t* P, float* dense_ms, float* lowrank_t_ms, float* lowrank_apply_ms) {
+    if (!P) return fail(NSGP_ERR_INVALID, "nsgp_plan_profile_detail: null plan");
+    if (dense_ms) *dense_ms = P->prof_detail[0];
+    if (lowrank_t_ms) *lowrank_t_ms = P->prof_detail[1];
+    if (lowrank_apply_ms) *lowrank_apply_ms = P->prof_detail[2];
     return NSGP_OK;
 }
 

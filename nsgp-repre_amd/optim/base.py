@@ -235,7 +235,7 @@ class NSCLOptimizerBase(Optimizer):
             U = V[:, :rank]
             if self.polish_basis:       # on the r head columns only: an r x r Gram matrix, once per layer per task
                 U = 1.5 * U - 0.5 * (U @ (U.t() @ U))
-            rpad = (rank + 31) // 32 * 32
+            rpad = 32 if rank <= 32 else (64 if rank <= 64 else 128)     # U's padded width (csrc: lr_rpad)
             U_rm = torch.zeros(D, rpad, dtype=torch.float32, device=V.device)
             U_rm[:, :rank] = U
             U_kq = U_rm.view(D // 4, 4, rpad).permute(0, 2, 1).contiguous()     # k-quads [D/4][rpad][4]
@@ -404,6 +404,17 @@ class NSCLOptimizerBase(Optimizer):
             _lib.check(lib.nsgp_plan_profile_end(plan["handle"], C.byref(n), C.byref(u), C.byref(g)), "nsgp_plan_profile_end")
             n_, u_, g_ = max(n_, n.value), u_ + u.value, g_ + g.value
         return n_, u_, g_
+
+    def profile_detail(self):
+        """The projection part of the last ``profile_end`` launch by launch: (dense GEMM ms, low-rank T ms, low-rank apply
+        ms), summed over plans."""
+        lib = _lib.load_library()
+        tot = [0.0, 0.0, 0.0]
+        for plan in self._plans:
+            a, b, c = C.c_float(), C.c_float(), C.c_float()
+            _lib.check(lib.nsgp_plan_profile_detail(plan["handle"], C.byref(a), C.byref(b), C.byref(c)), "nsgp_plan_profile_detail")
+            tot = [tot[0] + a.value, tot[1] + b.value, tot[2] + c.value]
+        return tuple(tot)
 
     def _validate(self, n, p, group):
         if p.grad is None:  # the reference dereferences p.grad.data unconditionally (:75)
