@@ -297,48 +297,46 @@ def roofline_block(split, flops, abytes_kernel, gemm_ms, update_ms, n_prof, nume
                    proj_numel=0, proj_bytes=0):
     """`roofline` of the NSGP step's dominant kernel, from HIP events the library records around each launch of the timed steps.
 
-    DEFAULT path (every projected layer on the low-rank form; `lowrank` = the plan's low-rank stats): the step is three
-    HBM-bound launches.  The longest is the multi-tensor update (`nsgp_update_kernel`: g r, buf r+w, p r+w = 20 B per element over
-    all 41.2 M elements) -> `bound: hbm`, `achieved` = those algorithmic bytes / its average duration, `peak` 8 TB/s.  The
-    two low-rank launches are blocks beside it, each against the same HBM peak with ITS algorithmic bytes (T = u U reads the
-    update once: 4 B per projected element; apply reads the update and reads + writes p: 12 B per projected element), and
+    DEFAULT path (every projected layer on the low-rank form; `lowrank` = the plan's low-rank stats, `detail` = per-launch ms):
+    the step is four launches, all HBM-bound.  The longest is the fused update + T launch of the 50 projected layers
+    (`nsgp_update_lr_kernel`: g r, buf r+w, p r = 16 B per projected element, with T = u U computed on the fp32 MFMA while the
+    stream is in flight) -> `bound: hbm`, `achieved` = those algorithmic bytes / its average duration, `peak` 8 TB/s.  The
+    other launches are blocks beside it, each against the same HBM peak with ITS algorithmic bytes (multi-tensor update of the
+    un-projected tensors: 20 B per element; apply: reads the update, reads + writes p = 12 B per projected element), and
     `dense_equivalent_tflops` says what rate a dense u @ P (sum 2 Cout D^2 = 118.3 GFLOP) would have needed to
-    finish in the time the low-rank launches take.
+    finish in the time the low-rank projection takes (fused launch's share not counted: reduce + apply).
 
     DENSE path (projectors assigned from outside, or low_rank = False): the grouped projection GEMM dominates -> `bound: mfma`,
     `achieved` = ALGORITHMIC FLOP/s = flops / the launch's average duration, `peak` = the dense peak of the matrix unit the kernel
     runs on; on the split paths every fp32 product is evaluated as three fp16 (six bf16) MFMA products, reported as
     `executed_mfma_utilisation`, never as `frac`."""
-    update_bytes = 5 * 4 * numel
-    upd = {"kernel": "nsgp_update_kernel<SGD> (multi-tensor elementwise update: weight decay, momentum, p += update for un-projected tensors)",
-           "bound": "hbm", "achieved": update_bytes / (update_ms * 1e-3) / 1e9, "peak": PEAK_HBM_GBS, "unit": "GB/s",
-           "kernel_ms": update_ms, "algorithmic_bytes": update_bytes,
-           "algorithmic_bytes_note": "g r, buf r+w, p r+w = 20 B per element over every listed tensor (41.2 M elements)"}
-    upd["frac"] = upd["achieved"] / PEAK_HBM_GBS
     f = _pmc_file()
     tr = json.load(open(f)) if f else {}
+
+    def hbm(kernel, ms, nbytes, note):
+        gbs = nbytes / (ms * 1e-3) / 1e9 if ms else 0.0
+        return {"kernel": kernel, "bound": "hbm", "achieved": gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": gbs / PEAK_HBM_GBS,
+                "kernel_ms": ms, "algorithmic_bytes": nbytes, "algorithmic_bytes_note": note}
     if lowrank and lowrank[0] == nproj and detail:
-        dense_ms, t_ms, apply_ms = detail
-        out = dict(upd)
-        out.update({"profiled_steps": n_prof, "layers": nproj, "traffic": tr.get("nsgp_update_kernel_hbm_bytes_per_launch"),
+        plain_ms, fused_ms, dense_ms, reduce_ms, apply_ms = detail
+        plain_numel = numel - proj_numel
+        out = hbm("nsgp_update_lr_kernel<SGD> (the projected layers' elementwise update fused with T = u U on the exact fp32 MFMA)",
+                  fused_ms, 16 * proj_numel, "g r, momentum buffer r+w, p r = 16 B per element of the 50 projected layers (26.6 M elements)")
+        out.update({"profiled_steps": n_prof, "layers": nproj, "traffic": tr.get("nsgp_update_lr_kernel_hbm_bytes_per_launch"),
                     "traffic_source": tr.get("source"),
-                    "nsgp_step_launches": "nsgp_update_kernel -> nsgp_lr_t_kernel (+ nsgp_lr_reduce_kernel) -> nsgp_lr_apply_kernel",
-                    "lowrank_t": {"kernel": "nsgp_lr_t_kernel<SGD> + nsgp_lr_reduce_kernel (T = u U, exact fp32 MFMA, K slices summed in order)",
-                                  "bound": "hbm", "kernel_ms": t_ms, "algorithmic_bytes": 4 * proj_numel,
-                                  "achieved": 4 * proj_numel / (t_ms * 1e-3) / 1e9, "peak": PEAK_HBM_GBS, "unit": "GB/s",
-                                  "frac": 4 * proj_numel / (t_ms * 1e-3) / 1e9 / PEAK_HBM_GBS,
-                                  "mfma_flops": lowrank[1] / 2, "mfma_tflops": lowrank[1] / 2 / (t_ms * 1e-3) / 1e12,
-                                  "mfma_frac_of_fp32_matrix_peak": lowrank[1] / 2 / (t_ms * 1e-3) / 1e12 / PEAK_FP32_MATRIX_TFLOPS,
-                                  "note": "reads the update once (4 B per projected element); 2*Cout*D*r FLOP on v_mfma_f32_32x32x2_f32"},
-                    "lowrank_apply": {"kernel": "nsgp_lr_apply_kernel<SGD> (p += c (u - T U^T), exact fp32 MFMA, K = r)",
-                                      "bound": "hbm", "kernel_ms": apply_ms, "algorithmic_bytes": 12 * proj_numel,
-                                      "achieved": 12 * proj_numel / (apply_ms * 1e-3) / 1e9, "peak": PEAK_HBM_GBS, "unit": "GB/s",
-                                      "frac": 12 * proj_numel / (apply_ms * 1e-3) / 1e9 / PEAK_HBM_GBS,
-                                      "note": "reads the update, reads and writes p (12 B per projected element)"},
+                    "mfma_flops": lowrank[1] / 2, "mfma_frac_of_fp32_matrix_peak": lowrank[1] / 2 / (fused_ms * 1e-3) / 1e12 / PEAK_FP32_MATRIX_TFLOPS,
+                    "nsgp_step_launches": "nsgp_update_kernel -> nsgp_update_lr_kernel -> nsgp_lr_reduce_kernel -> nsgp_lr_apply_kernel",
+                    "elementwise": hbm("nsgp_update_kernel<SGD> (multi-tensor update of the un-projected tensors)", plain_ms, 20 * plain_numel,
+                                       "g r, buf r+w, p r+w = 20 B per element of the un-projected tensors (14.6 M elements)"),
+                    "lowrank_reduce_ms": reduce_ms,
+                    "lowrank_apply": hbm("nsgp_lr_apply_kernel<SGD> (p += c (u - T U^T), exact fp32 MFMA, K = r)", apply_ms, 12 * proj_numel,
+                                         "reads the update, reads and writes p = 12 B per projected element"),
+                    "step_hbm_gbs": (16 * proj_numel + 20 * plain_numel + 12 * proj_numel) / ((plain_ms + fused_ms + reduce_ms + apply_ms) * 1e-3) / 1e9,
                     "lowrank_flops": lowrank[1], "dense_form_flops": flops,
-                    "dense_equivalent_tflops": flops / ((t_ms + apply_ms) * 1e-3) / 1e12,
-                    "dense_equivalent_note": "the rate a dense u @ P over the same layers (SURVEY 8d's 118.3 GFLOP) would need to match the low-rank "
-                                             "launches; the dense fp16-split kernel itself is timed under hot_path.mfma_paths / roofline_dense_f16x2"})
+                    "dense_equivalent_tflops": flops / ((reduce_ms + apply_ms) * 1e-3) / 1e12,
+                    "dense_equivalent_note": "the rate a dense u @ P over the same layers (SURVEY 8d's 118.3 GFLOP) would need to match the projection's own "
+                                             "launches (reduce + apply; T rides in the update launch); the dense fp16-split kernel itself is timed under "
+                                             "hot_path.mfma_paths / hot_path.roofline_dense_f16x2"})
         return out
     alg_tf = flops / (gemm_ms * 1e-3) / 1e12
     mult = {"bf16x3": 6, "f16x2": 3}.get(split, 1)
@@ -455,7 +453,7 @@ def end_to_end_training(N, dev, world, local_rank, basis_cache, steps, warmup, a
            "_roofline": dict(split=split, flops=flops, abytes_kernel=proj_bytes + 3 * 4 * proj_numel, gemm_ms=gemm_ms, update_ms=update_ms,
                              n_prof=n_prof, numel=all_numel, ntiles=ntiles, nproj=nproj, detail=detail, lowrank=lowrank,
                              proj_numel=proj_numel, proj_bytes=proj_bytes),
-           "nsgp_update_kernel_ms": update_ms, "nsgp_lowrank_t_ms": detail[1], "nsgp_lowrank_apply_ms": detail[2], "nsgp_dense_gemm_ms": detail[0],
+           "nsgp_launch_ms": dict(zip(("update", "update_lr_fused_t", "dense_gemm", "lowrank_reduce", "lowrank_apply"), detail)),
            "layers_on_low_rank_form": lowrank[0],
            "trainable_tensors": sum(len(g["params"]) for g in opt.param_groups),
            "losses_finite": finite, "loss_keys": sorted(losses.keys()),
@@ -542,16 +540,16 @@ def hot_path_only(N, dev, args, cache):
     ms, u_ms, g_ms = timed(args.steps)
     out["host_ms_in_optimizer_step"] = 1e3 * sum(host_step[-args.steps:]) / max(1, len(host_step[-args.steps:]))
     n_lr, lr_flops, lt1, lt2 = opt.lowrank_stats()
-    dense_ms, t_ms, a_ms = opt.profile_detail()
+    plain_ms, fused_ms, dense_ms, t_ms, a_ms = opt.profile_detail()
     flops = opt.plan_stats()[0]
     out["low_rank_form"] = {
-        "default": True, "ms_per_step": ms, "nsgp_step_ms": u_ms + g_ms, "elementwise_kernel_ms": u_ms, "lowrank_t_ms": t_ms, "lowrank_apply_ms": a_ms,
-        "projection_launches_ms": g_ms, "layers": n_lr, "removed_directions_per_width": {str(D): int(v[1]) for D, v in sorted(cache.items())},
+        "default": True, "ms_per_step": ms, "nsgp_step_ms": u_ms + g_ms, "update_kernel_ms": plain_ms, "update_lr_fused_t_kernel_ms": fused_ms,
+        "lowrank_reduce_ms": t_ms, "lowrank_apply_ms": a_ms, "projection_launches_ms": g_ms, "layers": n_lr, "removed_directions_per_width": {str(D): int(v[1]) for D, v in sorted(cache.items())},
         "lowrank_flops": lr_flops, "dense_form_flops": flops, "dense_equivalent_tflops": flops / (g_ms * 1e-3) / 1e12,
-        "elementwise_hbm_gbs": 5 * 4 * flat_numel_real / (u_ms * 1e-3) / 1e9,
-        "lowrank_t_hbm_gbs": 4 * proj_numel / (t_ms * 1e-3) / 1e9 if t_ms else None,
+        "update_hbm_gbs": 5 * 4 * (flat_numel_real - proj_numel) / (plain_ms * 1e-3) / 1e9 if plain_ms else None,
+        "update_lr_fused_t_hbm_gbs": 16 * proj_numel / (fused_ms * 1e-3) / 1e9 if fused_ms else None,
         "lowrank_apply_hbm_gbs": 12 * proj_numel / (a_ms * 1e-3) / 1e9 if a_ms else None,
-        "workgroups": {"lowrank_t": lt1, "lowrank_apply": lt2},
+        "workgroups": {"update_lr_fused_t": lt1, "lowrank_apply": lt2},
         "note": "parity: tests/test_gpu_parity.py::test_full_table_low_rank_default_vs_oracle_per_row, ::test_low_rank_form_matches_dense_form, ::test_g1b_default_pipeline_from_covariance_per_row"}
     # ---- the dense GEMM on every MFMA path, with the SAME projectors (what externally assigned projectors run on)
     opt.low_rank = False

@@ -153,13 +153,14 @@ int nsgp_plan_uses_split_mfma(const nsgp_plan_t* plan);
 int nsgp_plan_tile_counts(const nsgp_plan_t* plan, int* fast_128, int* generic_128, int* split_f16_256);
 
 /* Per-launch timing with HIP events recorded on the launch stream (measurement only): between
- * _begin and _end each nsgp_plan_step records 5 events; _end synchronises on them and returns
+ * _begin and _end each nsgp_plan_step records 6 events; _end synchronises on them and returns
  * the average duration of the elementwise launch and of the projection launches (dense GEMM and / or low-rank) together. */
 int nsgp_plan_profile_begin(nsgp_plan_t* plan, int max_steps);
 int nsgp_plan_profile_end(nsgp_plan_t* plan, int* n_steps, float* update_ms_avg, float* gemm_ms_avg);
-/* The projection part of the last _end, launch by launch (ABI 7): the dense GEMM launch(es), the low-rank T = u U launch
- * (+ its slab reduce), the low-rank apply launch; averages in ms over the profiled steps, 0 for launches a plan does not make. */
-int nsgp_plan_profile_detail(const nsgp_plan_t* plan, float* dense_ms, float* lowrank_t_ms, float* lowrank_apply_ms);
+/* The last _end launch by launch (ABI 7), averages in ms over the profiled steps, 0 for launches a plan does not make:
+ * ms5[0] the multi-tensor elementwise launch, [1] the fused update + T = u U launch of the low-rank layers, [2] the dense GEMM
+ * launch(es), [3] the slab reduce of the low-rank T, [4] the low-rank apply launch.  (_end's update_ms = [0] + [1], gemm_ms = the rest.) */
+int nsgp_plan_profile_detail(const nsgp_plan_t* plan, float* ms5);
 
 /* Three-term bf16 split of the TRANSPOSE of a projector (proj = sum of the three terms to 24 mantissa bits), in the layout
  * the split-MFMA projection kernel streams: [n][k/8][term][8] bf16, 6 bytes per element.  Once per projector per task.

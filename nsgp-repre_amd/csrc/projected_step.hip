@@ -83,9 +83,11 @@ struct ChunkDev {
     long start;
 };
 
-constexpr int CHUNK = 16384;  // elements per workgroup of the elementwise kernel
+constexpr int CHUNK = 4096;   // elements per workgroup of the elementwise kernel: 4 float4 rounds per thread.  (A workgroup is a chain of dependent
+                              // load -> store rounds; the kernel gets its bandwidth from the number of workgroups in flight, and with 16,384-element
+                              // chunks the 14.6 M un-projected elements of R-50-FPN were 3.5 workgroups per CU: 2.5 TB/s.)
 constexpr int NSLOT = 4;      // depth of the per-step upload ring
-constexpr int PROF_EV = 5;    // events per profiled step
+constexpr int PROF_EV = 6;    // events per profiled step
 
 struct DynBlock {  // uploaded every step: hyper sets + current grad pointers
     nsgp_hyper_t hyper[NSGP_MAX_HYPER];
@@ -410,17 +412,11 @@ __global__ __launch_bounds__(256, 2) void nsgp_project_single_kernel(const float
 // B[k'][j = l & 31], k' = l >> 5): at r <= 128 the matrix work is a few GFLOP per step and hides under the memory stream.
 // Both launches serve every rank class (U padded to rpad = 32, 64 or 128 columns) of a plan at once.
 //
-//   launch T  (nsgp_lr_t_kernel):      T[32 rows x rpad] = scale * (S U).  One workgroup of 8 waves per (32-row block,
-//             K range s of the layer's S): wave w takes the 32-column block jb = w % NJ of U (NJ = rpad / 32) and the
-//             K slice w / NJ of the range, so a wave holds ONE 32 x 32 accumulator whatever the rank.  Each lane loads
-//             16 B of its row per k8 step straight into the MFMA's A register (k = 8t + 4h + e on step e: ANY assignment
-//             of k to (step, lane half) is a valid contraction order as long as B uses the same one); U comes as k-quads
-//             [D/4][rpad][4], so a lane's B operand for four MFMAs is one coalesced 16-byte load.  The slices of a
-//             workgroup are summed in slice order through LDS; with S > 1 the result is a slab and a small launch
-//             (nsgp_lr_reduce_kernel) sums a layer's S slabs in range order -- bitwise deterministic.  S is chosen per layer
-//             so that no workgroup carries more than ~5 us of MFMAs (the 512 x 4608 layers would otherwise be 48 long
-//             workgroups).  (A "last workgroup to arrive sums the slabs" variant needs an agent-scope release / acquire
-//             per workgroup -- an L2 write-back + invalidate on a multi-XCD part -- and measured 0.77 ms.)
+//   launch U+T (nsgp_update_lr_kernel): the layer's elementwise update fused with T[32 rows x rpad] = scale * (S U), see the
+//             kernel.  Wide layers are cut into S K ranges (one workgroup each, ~32 groups of 32 columns) whose slabs a small
+//             launch (nsgp_lr_reduce_kernel) sums in range order.  (A "last workgroup to arrive sums the slabs" variant needs an
+//             agent-scope release / acquire per workgroup -- an L2 write-back + invalidate on a multi-XCD part -- and measured
+//             0.77 ms; a stand-alone T launch re-reading the update measured 0.063 ms, MFMA-latency bound.)
 //   launch A  (nsgp_lr_apply_kernel):  p += c * (scale*S - T U^T), K = rpad.  One workgroup per (32 rows x <= 256
 //             columns), the four waves on adjacent 32-column blocks: a wave loads S and p in the (transposed) MFMA C layout
 //             as 16-byte pieces, T and U rows as 16-byte fragments (L1 / L2 hits), does rpad/2 MFMAs and writes p.
@@ -437,7 +433,6 @@ __device__ __forceinline__ void lowrank_source(const LayerDev& L, const DynBlock
     }
 }
 
-constexpr int LRT_WAVES = 8;         // divisible by NJ = rpad / 32 in {1, 2, 4}; two workgroups per CU (114 VGPRs, 37 KB of LDS)
 constexpr int LRA_COLS = 256;        // columns of one apply workgroup
 static_assert(LRA_COLS == 256, "the apply kernel gives each of its four waves at most two 32-column blocks");
 constexpr int LR_MAX_RANK = 128;
@@ -458,75 +453,149 @@ __device__ __forceinline__ f32x4 lds_get4(const float* tile, int off) { return *
 // the MFMA wants lane (i = l & 31, h = l >> 5) to hold 16 bytes of row i.  (Loading in the MFMA layout directly -- 32 rows x 32
 // bytes per instruction, four instructions per line -- measured 0.12 ms for the apply launch against the stream's 0.06.)
 
+// Launch U+T: the elementwise update of a low-rank layer AND its T = (scale*S) U in one pass over the gradient stream.
+// One workgroup of 4 waves owns 32 rows x one K range (a run of 32-column groups) of a layer and walks it four groups at a
+// time.  Per round
+//   PRODUCE  wave w takes group gb + w (512 contiguous bytes per row across the workgroup): it loads g, the momentum buffer /
+//            Adam moments and p as 8 rows x 128 B per instruction, applies the same per-element arithmetic as nsgp_update_kernel
+//            (sgd_elem / adam_elem), stores the state (and the mutated gradient / Adam's update), and parks the 32 x 32 block of
+//            update values in LDS tile w of the round's buffer;
+//   one barrier (two tile buffers: the barrier of round k+1 also says that every wave is done reading the tiles of round k-1);
+//   CONSUME  wave w owns ONE 32-column block of U, jb = w mod NJ (NJ = rpad / 32 = 1, 2 or 4), and contracts NJ of the four
+//            tiles with it -- tiles (w div NJ) + (4 / NJ) x -- 16 x v_mfma_f32_32x32x2_f32 per tile into a single accumulator
+//            (U as k-quads: one coalesced 16-byte load per lane and k8 step, L2-resident, issued before the barrier).
+// Every wave therefore streams one group and does 16 NJ MFMAs per round whatever the rank: ONE kernel and ONE launch for all
+// rank classes, 16 accumulator registers.  The matrix work (2*Cout*D*r FLOP per step, ~20 us of the matrix pipe chip-wide)
+// hides under the HBM stream of the update, and the update values are never re-read for T.  At the end the waves that share a
+// column block are summed in wave order through LDS into T (one K range per layer) or into the range's slab
+// (nsgp_lr_reduce_kernel sums the slabs in range order): deterministic.
+// (First form: each wave contracted its own groups with ALL column blocks -- 16 NJ accumulator registers, a launch per rank
+// class, the U loads of blocks 1.. on the dependent chain: 78 us for each of the two wide classes of R-50-FPN.)
 template <int OPT>
-__global__ __launch_bounds__(LRT_WAVES * 64) void nsgp_lr_t_kernel(const TileDev* __restrict__ units, const LayerDev* __restrict__ layers,
-                                                                  const DynBlock* __restrict__ dyn) {
-    __shared__ __attribute__((aligned(16))) float lds[LRT_WAVES * LR_TILE];   // the waves' A tiles; afterwards the waves' partial T blocks (1024 floats each)
-    const TileDev t = units[blockIdx.x];           // m0 = first row, pad = K range index s
+__global__ __launch_bounds__(256) void nsgp_update_lr_kernel(const TileDev* __restrict__ units, const LayerDev* __restrict__ layers,
+                                                             const TensorDev* __restrict__ tensors, const DynBlock* __restrict__ dyn) {
+    __shared__ __attribute__((aligned(16))) float lds[8 * LR_TILE];   // 2 buffers x 4 tiles; afterwards the waves' partial T blocks (1024 floats each)
+    const TileDev t = units[blockIdx.x];           // m0 = first row, pad = K range index
     const LayerDev L = layers[t.layer];
-    const float* A;
-    float scale;
-    lowrank_source<OPT>(L, dyn, A, scale);
+    const TensorDev T = tensors[L.tensor];
+    const nsgp_hyper_t h = dyn->hyper[T.hyper];
+    float* __restrict__ gp = dyn->grads[L.tensor];
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int i = lane & 31, h = lane >> 5, r8 = lane >> 3, ch = lane & 7;
-    const int NJ = L.rpad >> 5, ksl = LRT_WAVES / NJ;
-    const int jb = wave % NJ, ks = wave / NJ;
+    const int i = lane & 31, hh = lane >> 5, r8 = lane >> 3, ch = lane & 7;
     const int ngroups = L.cols >> 5;               // groups of 32 k = one 128-byte line per row
-    const int per = (ngroups + L.nsplit * ksl - 1) / (L.nsplit * ksl);
-    const int g0 = min(ngroups, (t.pad * ksl + ks) * per), g1 = min(ngroups, g0 + per);
-    float* tile = lds + wave * LR_TILE;
-    const float* abase = A + (long)(t.m0 + r8) * L.cols + 4 * ch;          // + 8 it rows, + 32 g columns
-    const long a8 = 8L * L.cols;
-    const float* ub = L.ukq + ((long)h * L.rpad + jb * 32 + i) * 4;        // quad 8 g + 2 s + h, column 32 jb + i
-    const long qs = 2L * L.rpad * 4, qg = 8L * L.rpad * 4;                 // floats per k8 step, per group
+    const int per = (ngroups + L.nsplit - 1) / L.nsplit;
+    const int g0 = min(ngroups, t.pad * per), g1 = min(ngroups, g0 + per);
+    const int nj = L.rpad >> 5;                    // 1, 2 or 4
+    const int jb = wave & (nj - 1), sub = wave / nj, tstride = 4 / nj;
+    // what the projection reads as its A operand, and whether the mutated gradient must be stored (as in nsgp_update_kernel)
+    const bool a_is_buf = (OPT == NSGP_OPT_SGD) && h.momentum != 0.0f && !h.nesterov;
+    bool wg = h.write_grad != 0;
+    if (OPT == NSGP_OPT_SGD && !a_is_buf) wg = true;
+    const bool store_g = wg && (h.weight_decay != 0.0f || (OPT == NSGP_OPT_SGD && h.momentum != 0.0f && h.nesterov));
+    const bool need_p = h.weight_decay != 0.0f || h.decoupled_decay != 0.0f;
+    const float scale = (OPT == NSGP_OPT_SGD) ? -h.lr : 1.0f;
+    const long rowbase = (long)(t.m0 + r8) * L.cols + 4 * ch;             // + 8 it rows, + 32 g columns
+    const long r8s = 8L * L.cols;
+    const float* ub = L.ukq + ((long)hh * L.rpad + jb * 32 + i) * 4;      // quad 8 g + 2 st + hh, column 32 jb + i
+    const long qs = 2L * L.rpad * 4, qg = 8L * L.rpad * 4;                // floats per k8 step, per group
     f32x16 acc;
 #pragma unroll
     for (int v = 0; v < 16; ++v) acc[v] = 0.0f;
-    f32x4 a[2][4], b[2][4];
-    auto load = [&](int g, auto set_) {
-        constexpr int set = decltype(set_)::value;
+    // (Measured and not kept: requesting the NEXT round's stream before the barrier and the matrix work -- in front of or behind
+    // the U fragments, 8 or 16 groups per workgroup -- 128-134 us on the R-50 table either way, at 134 instead of 112 VGPRs: vmcnt
+    // retires in order, so every fragment wait inside the consume phase waits for the prefetched stream as well.)
+    int buf = 0;
+    for (int gb = g0; gb < g1; gb += 4, buf ^= 1) {
+        float* tiles = lds + buf * (4 * LR_TILE);
+        const int g = gb + wave;
+        if (g < g1) {
+            // ---- produce: the update of group g
+            f32x4 a4[4];
 #pragma unroll
-        for (int it = 0; it < 4; ++it) a[set][it] = load4_a4(abase + it * a8 + 32L * g);
+            for (int it = 0; it < 4; ++it) {
+                const long off = rowbase + it * r8s + 32L * g;
+                const f32x4 g4 = load4_a4(gp + off);
+                float gv[4] = {g4[0], g4[1], g4[2], g4[3]};
+                float pv[4] = {0, 0, 0, 0};
+                if (need_p) {
+                    const f32x4 p4 = *(const gf32x4*)(T.p + off);
+                    pv[0] = p4[0]; pv[1] = p4[1]; pv[2] = p4[2]; pv[3] = p4[3];
+                }
+                if (OPT == NSGP_OPT_SGD) {
+                    float bv[4] = {0, 0, 0, 0};
+                    if (h.momentum != 0.0f) {
+                        const f32x4 s4 = *(const gf32x4*)(T.s0 + off);
+                        bv[0] = s4[0]; bv[1] = s4[1]; bv[2] = s4[2]; bv[3] = s4[3];
+                    }
 #pragma unroll
-        for (int st = 0; st < 4; ++st) b[set][st] = *(const gf32x4*)(ub + g * qg + st * qs);
-    };
-    auto mma = [&](auto set_) {
-        constexpr int set = decltype(set_)::value;
+                    for (int e = 0; e < 4; ++e) sgd_elem(pv[e], gv[e], bv[e], h, true);
+                    if (h.momentum != 0.0f) *(gf32x4*)(T.s0 + off) = f32x4{bv[0], bv[1], bv[2], bv[3]};
+                    a4[it] = a_is_buf ? f32x4{bv[0], bv[1], bv[2], bv[3]} : f32x4{gv[0], gv[1], gv[2], gv[3]};
+                } else {
+                    const f32x4 m4 = *(const gf32x4*)(T.s0 + off), v4 = *(const gf32x4*)(T.s1 + off);
+                    float mv[4] = {m4[0], m4[1], m4[2], m4[3]}, vv[4] = {v4[0], v4[1], v4[2], v4[3]}, xv[4] = {0, 0, 0, 0}, uv[4];
+                    if (h.amsgrad) {
+                        const f32x4 x4 = *(const gf32x4*)(T.s2 + off);
+                        xv[0] = x4[0]; xv[1] = x4[1]; xv[2] = x4[2]; xv[3] = x4[3];
+                    }
 #pragma unroll
-        for (int it = 0; it < 4; ++it) lds_put4(tile, (r8 + 8 * it) * LR_TILE_LD + 4 * ch, a[set][it]);
-        f32x4 f[4];
+                    for (int e = 0; e < 4; ++e) adam_elem(pv[e], gv[e], mv[e], vv[e], xv[e], uv[e], h, true);
+                    *(gf32x4*)(T.s0 + off) = f32x4{mv[0], mv[1], mv[2], mv[3]};
+                    *(gf32x4*)(T.s1 + off) = f32x4{vv[0], vv[1], vv[2], vv[3]};
+                    if (h.amsgrad) *(gf32x4*)(T.s2 + off) = f32x4{xv[0], xv[1], xv[2], xv[3]};
+                    a4[it] = f32x4{uv[0], uv[1], uv[2], uv[3]};
+                    *(gf32x4*)(T.u + off) = a4[it];
+                }
+                if (store_g) *(gf32x4_a4*)(gp + off) = f32x4_a4{gv[0], gv[1], gv[2], gv[3]};
+            }
 #pragma unroll
-        for (int st = 0; st < 4; ++st) f[st] = lds_get4(tile, i * LR_TILE_LD + 4 * (2 * st + h));      // k = 32 g + 8 st + 4 h + e
-#pragma unroll
-        for (int st = 0; st < 4; ++st)
-#pragma unroll
-            for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(f[st][e], b[set][st][e], acc, 0, 0, 0);
-    };
-    if (g0 < g1) {
-        load(g0, IC<0>{});
-        int g = g0;
-        for (; g + 2 < g1; g += 2) {
-            load(g + 1, IC<1>{});
-            mma(IC<0>{});
-            load(g + 2, IC<0>{});
-            mma(IC<1>{});
+            for (int it = 0; it < 4; ++it) lds_put4(tiles + wave * LR_TILE, (r8 + 8 * it) * LR_TILE_LD + 4 * ch, a4[it]);
         }
-        if (g + 1 < g1) load(g + 1, IC<1>{});
-        mma(IC<0>{});
-        if (g + 1 < g1) mma(IC<1>{});
+        // ---- consume: my column block of U against nj of the round's tiles
+        f32x4 bx[2][4];                            // the fragments of tile x + 1 are requested while tile x is contracted
+        auto load_b = [&](int x, auto set_) {
+            constexpr int set = decltype(set_)::value;
+            const int gx = gb + sub + tstride * x;
+            if (x < nj && gx < g1) {
+#pragma unroll
+                for (int st = 0; st < 4; ++st) bx[set][st] = *(const gf32x4*)(ub + gx * qg + st * qs);
+            }
+        };
+        auto contract = [&](int x, auto set_) {
+            constexpr int set = decltype(set_)::value;
+            const int tx = sub + tstride * x;
+            if (x < nj && gb + tx < g1) {
+                f32x4 f[4];
+#pragma unroll
+                for (int st = 0; st < 4; ++st) f[st] = lds_get4(tiles + tx * LR_TILE, i * LR_TILE_LD + 4 * (2 * st + hh));   // k = 32 g + 8 st + 4 hh + e
+#pragma unroll
+                for (int st = 0; st < 4; ++st)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(f[st][e], bx[set][st][e], acc, 0, 0, 0);
+            }
+        };
+        load_b(0, IC<0>{});
+        __syncthreads();
+        load_b(1, IC<1>{});
+        contract(0, IC<0>{});
+        load_b(2, IC<0>{});
+        contract(1, IC<1>{});
+        load_b(3, IC<1>{});
+        contract(2, IC<0>{});
+        contract(3, IC<1>{});
     }
-    // the K slices of each column block, summed in slice order (deterministic)
-    __syncthreads();                               // every wave is done with its A tile: the buffer becomes the partial blocks
+    // the waves that share a column block (wave = sub * nj + jb), summed in wave order (deterministic)
+    __syncthreads();                               // every wave is done with the tiles: the buffer becomes four partial blocks
     float* mine = lds + wave * 1024;
 #pragma unroll
     for (int v = 0; v < 16; ++v) mine[acc_row(v, lane) * 32 + i] = acc[v];
     __syncthreads();
     float* dst = (L.nsplit > 1) ? L.slabs + (long)t.pad * L.rows * L.rpad : L.T;
     const float osc = (L.nsplit > 1) ? 1.0f : scale;
-    for (int idx = threadIdx.x; idx < NJ * 1024; idx += LRT_WAVES * 64) {
+    for (int idx = threadIdx.x; idx < nj * 1024; idx += 256) {
         const int j = idx >> 10, e = idx & 1023;                  // column block, element (row e >> 5, column e & 31)
-        float sum = lds[j * 1024 + e];                             // wave = ks * NJ + j
-        for (int k = 1; k < ksl; ++k) sum += lds[(k * NJ + j) * 1024 + e];
+        float sum = lds[j * 1024 + e];
+        for (int k = 1; k < tstride; ++k) sum += lds[(k * nj + j) * 1024 + e];
         as_global(dst)[(long)(t.m0 + (e >> 5)) * L.rpad + j * 32 + (e & 31)] = osc * sum;
     }
 }
@@ -654,7 +723,7 @@ struct nsgp_plan {
     TensorDev* d_tensors = nullptr;
     LayerDev* d_layers = nullptr;
     TileDev* d_tiles = nullptr;  // dense fast tiles | dense generic tiles | low-rank phase-1 | phase-2
-    int n_tiles_lr1 = 0, n_tiles_lr2 = 0, n_lowrank = 0;    // low-rank: workgroups of launch T and of launch A
+    int n_tiles_lr1 = 0, n_tiles_lr2 = 0, n_lowrank = 0;    // low-rank: workgroups of the fused update + T launches and of the apply launch
     int n_chunks_lr = 0;
     ChunkDev* d_chunks_lr = nullptr;
     double lowrank_flops = 0;
@@ -665,11 +734,11 @@ struct nsgp_plan {
     hipEvent_t ev[NSLOT] = {nullptr, nullptr, nullptr, nullptr};
     bool ev_used[NSLOT] = {false, false, false, false};
     int slot = 0;
-    // optional per-launch timing: PROF_EV events per recorded step (before the update launch, after it, after the dense GEMM
-    // launches, after the low-rank T (+ reduce) launches, after the low-rank apply launch)
+    // optional per-launch timing: PROF_EV events per recorded step (before the elementwise launch, after it, after the fused
+    // update + T launch of the low-rank layers, after the dense GEMM launches, after the slab reduce, after the low-rank apply launch)
     std::vector<hipEvent_t> prof_ev;
     int prof_cap = 0, prof_n = 0;
-    float prof_detail[3] = {0, 0, 0};   // averages of the last profile_end: dense GEMM, low-rank T (+ reduce), low-rank apply
+    float prof_detail[5] = {0, 0, 0, 0, 0};   // averages of the last profile_end: elementwise, fused update + T, dense GEMM, slab reduce, low-rank apply
 };
 
 static bool tensor_fast(const nsgp_tensor_t& t) {
@@ -685,14 +754,17 @@ static size_t pad256(size_t x) { return (x + 255) & ~(size_t)255; }
 // low-rank form: a head-form projector (the caller vouches that proj == basis_scale * (I - U U^T)), r <= 128, 32-aligned shape
 static bool tensor_lowrank(const nsgp_tensor_t& t) {
     return t.basis && t.basis_rows && t.rank > 0 && t.rank <= LR_MAX_RANK && t.rows % 32 == 0 && t.cols % 32 == 0 &&
-           aligned16(t.basis) && aligned16(t.basis_rows) && t.proj;
+           aligned16(t.basis) && aligned16(t.basis_rows) && t.proj && aligned16(t.param) && aligned16(t.state0) && aligned16(t.state1) &&
+           aligned16(t.state2);
 }
 static int lr_rpad(int rank) { return rank <= 32 ? 32 : (rank <= 64 ? 64 : 128); }   // U's padded width: 32, 64 or 128 columns
-// K ranges of a low-rank layer's T launch: a workgroup's MFMA time is (D/8 k8-steps) x 4 MFMAs x 64 clk x NJ column blocks
-// over 4 SIMDs = D * NJ * 8 clk; keep it under ~12,000 clk (5 us)
+// K ranges of a low-rank layer in the fused update + T launch: ~8 groups of 32 columns per workgroup (2 per wave), at most 16
+// ranges.  (32 groups per workgroup left the two wide rank classes of R-50-FPN with 240 workgroups each -- under one per CU --
+// and 78 us apiece; the slabs this costs are a few MB.)
 static int lr_nsplit(int cols, int rank) {
-    const long clk = (long)cols * (lr_rpad(rank) / 32) * 8;
-    return (int)std::max<long>(1, std::min<long>(16, (clk + 11999) / 12000));
+    (void)rank;
+    const int groups = cols / 32;
+    return std::max(1, std::min(16, (groups + 7) / 8));
 }
 static size_t lr_workspace(const nsgp_tensor_t& t) {
     const size_t one = pad256((size_t)t.rows * lr_rpad(t.rank) * 4);
@@ -786,6 +858,7 @@ extern "C" int nsgp_plan_create(nsgp_plan_t** out, const nsgp_tensor_t* tensors,
         }
         bytes += 5.0 * 4.0 * (double)t.numel;
         td[i] = d;
+        if (t.proj && tensor_lowrank(t)) continue;                                                           // updated by the fused update + T launch
         if (d.a_split) for (long s = 0; s < t.numel; s += 8L * t.cols) cd.push_back(ChunkDev{i, 1, s});   // 8-row bands
         else for (long s = 0; s < t.numel; s += CHUNK) cd.push_back(ChunkDev{i, 0, s});
     }
@@ -914,8 +987,10 @@ extern "C" int nsgp_plan_create(nsgp_plan_t** out, const nsgp_tensor_t* tensors,
     } while (0)
     PLAN_HIP(hipMalloc(&P->d_tensors, sizeof(TensorDev) * td.size()));
     PLAN_HIP(hipMemcpy(P->d_tensors, td.data(), sizeof(TensorDev) * td.size(), hipMemcpyHostToDevice));
-    PLAN_HIP(hipMalloc(&P->d_chunks, sizeof(ChunkDev) * cd.size()));
-    PLAN_HIP(hipMemcpy(P->d_chunks, cd.data(), sizeof(ChunkDev) * cd.size(), hipMemcpyHostToDevice));
+    if (!cd.empty()) {
+        PLAN_HIP(hipMalloc(&P->d_chunks, sizeof(ChunkDev) * cd.size()));
+        PLAN_HIP(hipMemcpy(P->d_chunks, cd.data(), sizeof(ChunkDev) * cd.size(), hipMemcpyHostToDevice));
+    }
     if (!lr_chunks.empty()) {
         PLAN_HIP(hipMalloc(&P->d_chunks_lr, sizeof(ChunkDev) * lr_chunks.size()));
         PLAN_HIP(hipMemcpy(P->d_chunks_lr, lr_chunks.data(), sizeof(ChunkDev) * lr_chunks.size(), hipMemcpyHostToDevice));
@@ -1049,12 +1124,23 @@ extern "C" int nsgp_plan_step(nsgp_plan_t* P, float* const* grads, const nsgp_hy
     const bool prof = P->prof_n < P->prof_cap;
     if (prof) NSGP_HIP(hipEventRecord(P->prof_ev[PROF_EV * P->prof_n + 0], stream));
 
-    if (P->optimizer == NSGP_OPT_SGD)
-        hipLaunchKernelGGL(nsgp_update_kernel<NSGP_OPT_SGD>, dim3(P->n_chunks), dim3(256), 0, stream, P->d_chunks, P->d_tensors, d);
-    else
-        hipLaunchKernelGGL(nsgp_update_kernel<NSGP_OPT_ADAM>, dim3(P->n_chunks), dim3(256), 0, stream, P->d_chunks, P->d_tensors, d);
-    NSGP_LAUNCH_CHECK();
+    if (P->n_chunks > 0) {
+        if (P->optimizer == NSGP_OPT_SGD)
+            hipLaunchKernelGGL(nsgp_update_kernel<NSGP_OPT_SGD>, dim3(P->n_chunks), dim3(256), 0, stream, P->d_chunks, P->d_tensors, d);
+        else
+            hipLaunchKernelGGL(nsgp_update_kernel<NSGP_OPT_ADAM>, dim3(P->n_chunks), dim3(256), 0, stream, P->d_chunks, P->d_tensors, d);
+        NSGP_LAUNCH_CHECK();
+    }
     if (prof) NSGP_HIP(hipEventRecord(P->prof_ev[PROF_EV * P->prof_n + 1], stream));
+    if (P->n_tiles_lr1 > 0) {      // low-rank layers: their update, fused with T = u U
+        const TileDev* t1 = P->d_tiles + P->n_tiles_fast + P->n_tiles_generic;
+        if (P->optimizer == NSGP_OPT_SGD)
+            hipLaunchKernelGGL(nsgp_update_lr_kernel<NSGP_OPT_SGD>, dim3(P->n_tiles_lr1), dim3(256), 0, stream, t1, P->d_layers, P->d_tensors, d);
+        else
+            hipLaunchKernelGGL(nsgp_update_lr_kernel<NSGP_OPT_ADAM>, dim3(P->n_tiles_lr1), dim3(256), 0, stream, t1, P->d_layers, P->d_tensors, d);
+        NSGP_LAUNCH_CHECK();
+    }
+    if (prof) NSGP_HIP(hipEventRecord(P->prof_ev[PROF_EV * P->prof_n + 2], stream));
     if (P->n_tiles_v2 > 0) {
         const TileDev* vt = P->d_tiles + P->n_tiles_fast + P->n_tiles_generic + P->n_tiles_lr1 + P->n_tiles_lr2;
         if (P->optimizer == NSGP_OPT_SGD)
@@ -1083,20 +1169,14 @@ extern "C" int nsgp_plan_step(nsgp_plan_t* P, float* const* grads, const nsgp_hy
             hipLaunchKernelGGL((nsgp_project_kernel<NSGP_OPT_ADAM, false>), dim3(P->n_tiles_generic), dim3(THREADS), SMEM_BYTES, stream, gt, P->d_layers, d);
         NSGP_LAUNCH_CHECK();
     }
-    if (prof) NSGP_HIP(hipEventRecord(P->prof_ev[PROF_EV * P->prof_n + 2], stream));
+    if (prof) NSGP_HIP(hipEventRecord(P->prof_ev[PROF_EV * P->prof_n + 3], stream));
     if (P->n_tiles_lr1 > 0) {
-        const TileDev* t1 = P->d_tiles + P->n_tiles_fast + P->n_tiles_generic;
-        const TileDev* t2 = t1 + P->n_tiles_lr1;
-        if (P->optimizer == NSGP_OPT_SGD)
-            hipLaunchKernelGGL(nsgp_lr_t_kernel<NSGP_OPT_SGD>, dim3(P->n_tiles_lr1), dim3(LRT_WAVES * 64), 0, stream, t1, P->d_layers, d);
-        else
-            hipLaunchKernelGGL(nsgp_lr_t_kernel<NSGP_OPT_ADAM>, dim3(P->n_tiles_lr1), dim3(LRT_WAVES * 64), 0, stream, t1, P->d_layers, d);
-        NSGP_LAUNCH_CHECK();
+        const TileDev* t2 = P->d_tiles + P->n_tiles_fast + P->n_tiles_generic + P->n_tiles_lr1;
         if (P->n_chunks_lr > 0) {
             hipLaunchKernelGGL(nsgp_lr_reduce_kernel, dim3(P->n_chunks_lr), dim3(256), 0, stream, P->d_chunks_lr, P->d_layers, d, P->optimizer);
             NSGP_LAUNCH_CHECK();
         }
-        if (prof) NSGP_HIP(hipEventRecord(P->prof_ev[PROF_EV * P->prof_n + 3], stream));
+        if (prof) NSGP_HIP(hipEventRecord(P->prof_ev[PROF_EV * P->prof_n + 4], stream));
         if (P->optimizer == NSGP_OPT_SGD)
             hipLaunchKernelGGL(nsgp_lr_apply_kernel<NSGP_OPT_SGD>, dim3(P->n_tiles_lr2), dim3(256), 0, stream, t2, P->d_layers, d);
         else
@@ -1104,8 +1184,8 @@ extern "C" int nsgp_plan_step(nsgp_plan_t* P, float* const* grads, const nsgp_hy
         NSGP_LAUNCH_CHECK();
     }
     if (prof) {
-        if (P->n_tiles_lr1 == 0) NSGP_HIP(hipEventRecord(P->prof_ev[PROF_EV * P->prof_n + 3], stream));
-        NSGP_HIP(hipEventRecord(P->prof_ev[PROF_EV * P->prof_n + 4], stream));
+        if (P->n_tiles_lr1 == 0) NSGP_HIP(hipEventRecord(P->prof_ev[PROF_EV * P->prof_n + 4], stream));
+        NSGP_HIP(hipEventRecord(P->prof_ev[PROF_EV * P->prof_n + 5], stream));
         ++P->prof_n;
     }
     NSGP_HIP(hipEventRecord(P->ev[s], stream));
@@ -1127,19 +1207,21 @@ extern "C" int nsgp_plan_profile_begin(nsgp_plan_t* P, int max_steps) {
 
 extern "C" int nsgp_plan_profile_end(nsgp_plan_t* P, int* n_steps, float* update_ms_avg, float* gemm_ms_avg) {
     if (!P) return fail(NSGP_ERR_INVALID, "nsgp_plan_profile_end: null plan");
-    double u = 0, g = 0, det[3] = {0, 0, 0};
+    // update_ms = both elementwise launches (the multi-tensor kernel + the fused update + T kernel of the low-rank layers);
+    // gemm_ms = everything behind them (dense GEMM launches, slab reduce, low-rank apply)
+    double u = 0, g = 0, det[5] = {0, 0, 0, 0, 0};
     for (int i = 0; i < P->prof_n; ++i) {
         hipEvent_t* e = &P->prof_ev[PROF_EV * i];
-        NSGP_HIP(hipEventSynchronize(e[4]));
-        float a = 0, b = 0, d3[3] = {0, 0, 0};
-        NSGP_HIP(hipEventElapsedTime(&a, e[0], e[1]));
-        NSGP_HIP(hipEventElapsedTime(&b, e[1], e[4]));
-        for (int k = 0; k < 3; ++k) NSGP_HIP(hipEventElapsedTime(&d3[k], e[1 + k], e[2 + k]));
+        NSGP_HIP(hipEventSynchronize(e[5]));
+        float a = 0, b = 0, d5[5] = {0, 0, 0, 0, 0};
+        NSGP_HIP(hipEventElapsedTime(&a, e[0], e[2]));
+        NSGP_HIP(hipEventElapsedTime(&b, e[2], e[5]));
+        for (int k = 0; k < 5; ++k) NSGP_HIP(hipEventElapsedTime(&d5[k], e[k], e[k + 1]));
         u += a;
         g += b;
-        for (int k = 0; k < 3; ++k) det[k] += d3[k];
+        for (int k = 0; k < 5; ++k) det[k] += d5[k];
     }
-    for (int k = 0; k < 3; ++k) P->prof_detail[k] = P->prof_n ? (float)(det[k] / P->prof_n) : 0.0f;
+    for (int k = 0; k < 5; ++k) P->prof_detail[k] = P->prof_n ? (float)(det[k] / P->prof_n) : 0.0f;
     if (n_steps) *n_steps = P->prof_n;
     if (update_ms_avg) *update_ms_avg = P->prof_n ? (float)(u / P->prof_n) : 0.0f;
     if (gemm_ms_avg) *gemm_ms_avg = P->prof_n ? (float)(g / P->prof_n) : 0.0f;
@@ -1148,11 +1230,9 @@ extern "C" int nsgp_plan_profile_end(nsgp_plan_t* P, int* n_steps, float* update
     return NSGP_OK;
 }
 
-extern "C" int nsgp_plan_profile_detail(const nsgp_plan_t* P, float* dense_ms, float* lowrank_t_ms, float* lowrank_apply_ms) {
-    if (!P) return fail(NSGP_ERR_INVALID, "nsgp_plan_profile_detail: null plan");
-    if (dense_ms) *dense_ms = P->prof_detail[0];
-    if (lowrank_t_ms) *lowrank_t_ms = P->prof_detail[1];
-    if (lowrank_apply_ms) *lowrank_apply_ms = P->prof_detail[2];
+extern "C" int nsgp_plan_profile_detail(const nsgp_plan_t* P, float* ms5) {
+    if (!P || !ms5) return fail(NSGP_ERR_INVALID, "nsgp_plan_profile_detail: null argument");
+    for (int k = 0; k < 5; ++k) ms5[k] = P->prof_detail[k];
     return NSGP_OK;
 }
 

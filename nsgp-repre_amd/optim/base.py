@@ -406,14 +406,14 @@ class NSCLOptimizerBase(Optimizer):
         return n_, u_, g_
 
     def profile_detail(self):
-        """The projection part of the last ``profile_end`` launch by launch: (dense GEMM ms, low-rank T ms, low-rank apply
-        ms), summed over plans."""
+        """The last ``profile_end`` launch by launch, ms summed over plans: (multi-tensor elementwise launch, fused update + T
+        launch of the low-rank layers, dense GEMM launches, slab reduce, low-rank apply launch)."""
         lib = _lib.load_library()
-        tot = [0.0, 0.0, 0.0]
+        tot = [0.0] * 5
         for plan in self._plans:
-            a, b, c = C.c_float(), C.c_float(), C.c_float()
-            _lib.check(lib.nsgp_plan_profile_detail(plan["handle"], C.byref(a), C.byref(b), C.byref(c)), "nsgp_plan_profile_detail")
-            tot = [tot[0] + a.value, tot[1] + b.value, tot[2] + c.value]
+            ms = (C.c_float * 5)()
+            _lib.check(lib.nsgp_plan_profile_detail(plan["handle"], ms), "nsgp_plan_profile_detail")
+            tot = [a + b for a, b in zip(tot, ms)]
         return tuple(tot)
 
     def _validate(self, n, p, group):

@@ -20,6 +20,11 @@ def main():
     steps = int(sys.argv[2]) if len(sys.argv) > 2 else 20
     dev = torch.device("cuda:0")
     layers = O.resnet_fpn_projected_layers(depth)
+    if os.environ.get("LR_SHAPES"):      # study aid: "rows,D,count[;rows,D,count...]" replaces the table (1x1 convolutions)
+        layers = []
+        for spec in os.environ["LR_SHAPES"].split(";"):
+            r, D, c = (int(x) for x in spec.split(","))
+            layers += [(f"neck.lateral_convs.{len(layers) + i}.conv.weight", r, D) for i in range(c)]
     basis = {}
     for n, cout, D in layers:
         if D in basis:
@@ -33,12 +38,12 @@ def main():
         del X, lam, Q
     print("removed directions per width:", {D: b[1] for D, b in sorted(basis.items())}, flush=True)
     out = {}
-    for kind in ("sgd", "adamw"):
-        for low in (True, False):
+    for kind in (("sgd",) if os.environ.get("LR_SHAPES") else ("sgd", "adamw")):
+        for low in ((True,) if os.environ.get("LR_SHAPES") else (True, False)):
             gen = torch.Generator(device=dev).manual_seed(7)
             params, names = [], []
             for n, cout, D in layers:
-                k = 3 if ("conv2" in n or "fpn_convs" in n) else 1
+                k = 3 if (("conv2" in n or "fpn_convs" in n) and not os.environ.get("LR_SHAPES")) else 1
                 params.append(torch.nn.Parameter(torch.randn(cout, D // (k * k), k, k, device=dev, generator=gen) * 0.02))
                 names.append(n)
             for i in range(112):   # the un-projected tensors of the table (BN, biases, heads): ~14.6 M elements
