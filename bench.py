@@ -299,10 +299,12 @@ def roofline_block(split, flops, abytes_kernel, gemm_ms, update_ms, n_prof, nume
 
     DEFAULT path (every projected layer on the low-rank form; `lowrank` = the plan's low-rank stats, `detail` = per-launch ms):
     the step is four launches, all HBM-bound.  The longest is the fused update + T launch of the 50 projected layers
-    (`nsgp_update_lr_kernel`: g r, buf r+w, p r = 16 B per projected element, with T = u U computed on the fp32 MFMA while the
-    stream is in flight) -> `bound: hbm`, `achieved` = those algorithmic bytes / its average duration, `peak` 8 TB/s.  The
+    (`nsgp_update_lr_kernel`: g r+w, buf r+w, p r = 20 B per projected element -- the gradient is written back because the
+    reference mutates p.grad in place (`grad.add_(wd, p)`, SGD_NSCL.py:400) and the optimizer mirrors that by default -- with
+    T = u U computed on the fp32 MFMA while the stream is in flight) -> `bound: hbm`, `achieved` = those algorithmic bytes / its
+    average duration, `peak` 8 TB/s, `traffic` = the HBM bytes rocprofv3's FETCH_SIZE / WRITE_SIZE counters saw per launch.  The
     other launches are blocks beside it, each against the same HBM peak with ITS algorithmic bytes (multi-tensor update of the
-    un-projected tensors: 20 B per element; apply: reads the update, reads + writes p = 12 B per projected element), and
+    un-projected tensors: 24 B per element; apply: reads the update, reads + writes p = 12 B per projected element), and
     `dense_equivalent_tflops` says what rate a dense u @ P (sum 2 Cout D^2 = 118.3 GFLOP) would have needed to
     finish in the time the low-rank projection takes (fused launch's share not counted: reduce + apply).
 
@@ -321,17 +323,21 @@ def roofline_block(split, flops, abytes_kernel, gemm_ms, update_ms, n_prof, nume
         plain_ms, fused_ms, dense_ms, reduce_ms, apply_ms = detail
         plain_numel = numel - proj_numel
         out = hbm("nsgp_update_lr_kernel<SGD> (the projected layers' elementwise update fused with T = u U on the exact fp32 MFMA)",
-                  fused_ms, 16 * proj_numel, "g r, momentum buffer r+w, p r = 16 B per element of the 50 projected layers (26.6 M elements)")
+                  fused_ms, 20 * proj_numel, "g r+w (the reference's in-place grad.add_(wd, p), mirrored), momentum buffer r+w, p r = 20 B per element "
+                                             "of the 50 projected layers (26.6 M elements)")
         out.update({"profiled_steps": n_prof, "layers": nproj, "traffic": tr.get("nsgp_update_lr_kernel_hbm_bytes_per_launch"),
                     "traffic_source": tr.get("source"),
                     "mfma_flops": lowrank[1] / 2, "mfma_frac_of_fp32_matrix_peak": lowrank[1] / 2 / (fused_ms * 1e-3) / 1e12 / PEAK_FP32_MATRIX_TFLOPS,
                     "nsgp_step_launches": "nsgp_update_kernel -> nsgp_update_lr_kernel -> nsgp_lr_reduce_kernel -> nsgp_lr_apply_kernel",
-                    "elementwise": hbm("nsgp_update_kernel<SGD> (multi-tensor update of the un-projected tensors)", plain_ms, 20 * plain_numel,
-                                       "g r, buf r+w, p r+w = 20 B per element of the un-projected tensors (14.6 M elements)"),
+                    "elementwise": hbm("nsgp_update_kernel<SGD> (multi-tensor update of the un-projected tensors)", plain_ms, 24 * plain_numel,
+                                       "g r+w, buf r+w, p r+w = 24 B per element of the un-projected tensors (14.6 M elements)"),
                     "lowrank_reduce_ms": reduce_ms,
                     "lowrank_apply": hbm("nsgp_lr_apply_kernel<SGD> (p += c (u - T U^T), exact fp32 MFMA, K = r)", apply_ms, 12 * proj_numel,
                                          "reads the update, reads and writes p = 12 B per projected element"),
-                    "step_hbm_gbs": (16 * proj_numel + 20 * plain_numel + 12 * proj_numel) / ((plain_ms + fused_ms + reduce_ms + apply_ms) * 1e-3) / 1e9,
+                    "step_algorithmic_bytes": 20 * proj_numel + 24 * plain_numel + 12 * proj_numel,
+                    "step_hbm_gbs": (20 * proj_numel + 24 * plain_numel + 12 * proj_numel) / ((plain_ms + fused_ms + reduce_ms + apply_ms) * 1e-3) / 1e9,
+                    "lowrank_apply_traffic": tr.get("nsgp_lr_apply_kernel_hbm_bytes_per_launch"),
+                    "mfma_busy_fraction_pmc": tr.get("nsgp_update_lr_kernel_mfma_busy_fraction"),
                     "lowrank_flops": lowrank[1], "dense_form_flops": flops,
                     "dense_equivalent_tflops": flops / ((reduce_ms + apply_ms) * 1e-3) / 1e12,
                     "dense_equivalent_note": "the rate a dense u @ P over the same layers (SURVEY 8d's 118.3 GFLOP) would need to match the projection's own "
@@ -514,7 +520,7 @@ def hot_path_only(N, dev, args, cache):
         loss = replay.replay_loss(replay.bbox_featss)["replay_loss"]["replay_loss_cls"]   # RePRE replay loss: forward
         loss.backward()                        # + backward: accumulates into the head's grad views
         h0 = time.perf_counter()
-        opt.step()                             # NSGP projected step: 2 HIP launches
+        opt.step()                             # NSGP projected step: 4 HIP launches on the default path
         host_step.append(time.perf_counter() - h0)
 
     def timed(steps):
@@ -546,8 +552,9 @@ def hot_path_only(N, dev, args, cache):
         "default": True, "ms_per_step": ms, "nsgp_step_ms": u_ms + g_ms, "update_kernel_ms": plain_ms, "update_lr_fused_t_kernel_ms": fused_ms,
         "lowrank_reduce_ms": t_ms, "lowrank_apply_ms": a_ms, "projection_launches_ms": g_ms, "layers": n_lr, "removed_directions_per_width": {str(D): int(v[1]) for D, v in sorted(cache.items())},
         "lowrank_flops": lr_flops, "dense_form_flops": flops, "dense_equivalent_tflops": flops / (g_ms * 1e-3) / 1e12,
-        "update_hbm_gbs": 5 * 4 * (flat_numel_real - proj_numel) / (plain_ms * 1e-3) / 1e9 if plain_ms else None,
-        "update_lr_fused_t_hbm_gbs": 16 * proj_numel / (fused_ms * 1e-3) / 1e9 if fused_ms else None,
+        "update_hbm_gbs": 24 * (flat_numel_real - proj_numel) / (plain_ms * 1e-3) / 1e9 if plain_ms else None,
+        "update_lr_fused_t_hbm_gbs": 20 * proj_numel / (fused_ms * 1e-3) / 1e9 if fused_ms else None,
+        "bytes_note": "update: g r+w, buf r+w, p r+w = 24 B/element; fused update + T: g r+w, buf r+w, p r = 20 B/element; apply: u r, p r+w = 12 B/element",
         "lowrank_apply_hbm_gbs": 12 * proj_numel / (a_ms * 1e-3) / 1e9 if a_ms else None,
         "workgroups": {"update_lr_fused_t": lt1, "lowrank_apply": lt2},
         "note": "parity: tests/test_gpu_parity.py::test_full_table_low_rank_default_vs_oracle_per_row, ::test_low_rank_form_matches_dense_form, ::test_g1b_default_pipeline_from_covariance_per_row"}

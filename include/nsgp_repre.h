@@ -54,11 +54,14 @@ int nsgp_debug_install_abort_backtrace(void);
  *   AdamWNSCL.step    mmdet/engine/optimizers/AdamW_NSCL.py:66-103 (+ get_update :212-250)
  *   AdamNSCL.step     mmdet/engine/optimizers/Adam_NSCL.py:66-102  (+ get_update :207-247)
  *   SGDNSCLNA.step    mmdet/engine/optimizers/SGD_NSCL_NoAdaptive.py:59-111
- * by two launches: one multi-tensor elementwise kernel over every listed
+ * by a handful of launches: one multi-tensor elementwise kernel over every listed
  * tensor (momentum / Adam moments / weight decay, `p += update` for the
- * un-projected ones) and one grouped MFMA GEMM `p += update.view(Cout,D) @ P`
- * over every projected tensor (the `torch.mm(update.view(Cout,-1), P)` of
- * SGD_NSCL.py:85-90).
+ * un-projected ones), and for the projected tensors either
+ *   - the low-rank form `p += c (u - (u U) U^T)` for layers described with `basis` / `basis_rows`
+ *     (head-form projectors, at most 128 removed directions): their elementwise update fused with
+ *     T = u U, a small ordered slab reduce, and the apply launch -- HBM-bound, exact fp32 MFMA; or
+ *   - one grouped MFMA GEMM `p += update.view(Cout,D) @ P` (the `torch.mm(update.view(Cout,-1), P)`
+ *     of SGD_NSCL.py:85-90) for every other projected tensor.
  * ------------------------------------------------------------------------ */
 
 typedef struct nsgp_plan nsgp_plan_t;

@@ -16,7 +16,7 @@ OURS = ("nsgp_", "repre_", "nsgp::")
 
 
 def short(name):
-    for key in ("nsgp_project_v2_kernel", "nsgp_lowrank_p1_kernel", "nsgp_lowrank_p2_kernel", "nsgp_lowrank_reduce_kernel", "nsgp_project_kernel", "nsgp_update_kernel", "nsgp_project_single_kernel", "nsgp_projector_kernel",
+    for key in ("nsgp_project_v2_kernel", "nsgp_update_lr_kernel", "nsgp_lr_apply_kernel", "nsgp_lr_reduce_kernel", "nsgp_projector_head_kernel", "nsgp_project_kernel", "nsgp_update_kernel", "nsgp_project_single_kernel", "nsgp_projector_kernel",
                 "nsgp_cov_syrk_kernel", "nsgp_cov_reduce_kernel", "nsgp_batch_mean_pad_kernel", "repre_sim_mask_kernel",
                 "repre_row_norm_kernel", "repre_masked_sum_kernel"):
         if key in name:
@@ -69,20 +69,28 @@ print("summaries written to", dst)
 # prescribes: FETCH_SIZE is in KiB and reads exactly 1/2 of a wide (16 B/lane) coalesced stream on
 # gfx950 -> x2; WRITE_SIZE (KiB) is exact for 16-B-per-lane / dword stores.
 import json
+
+
+def mean(v):
+    return sum(v) / len(v)
+
+
+traffic = {"source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE passes (kernels matching nsgp|repre only) of `python3 bench.py --steps 10 --warmup 2 "
+                     "--hot-path-only` (tools/profile.sh); FETCH_SIZE x2 per the gfx950 correction"}
 for k in agg:
-    if "nsgp_project_v2_kernel<0>" not in k and "nsgp_project_v2_kernelILi0" not in k:
-        continue
-    if "FETCH_SIZE" in agg[k] and "WRITE_SIZE" in agg[k]:
-        f = sum(agg[k]["FETCH_SIZE"]) / len(agg[k]["FETCH_SIZE"])
-        w = sum(agg[k]["WRITE_SIZE"]) / len(agg[k]["WRITE_SIZE"])
-        extra = {}
+    for tag, key in (("nsgp_project_v2_kernel<0>", "nsgp_project_kernel"), ("nsgp_update_lr_kernel<0>", "nsgp_update_lr_kernel"),
+                     ("nsgp_lr_apply_kernel<0>", "nsgp_lr_apply_kernel"), ("nsgp_update_kernel<0>", "nsgp_update_kernel")):
+        if tag not in k:
+            continue
+        if "FETCH_SIZE" in agg[k] and "WRITE_SIZE" in agg[k]:
+            f, w = mean(agg[k]["FETCH_SIZE"]), mean(agg[k]["WRITE_SIZE"])
+            traffic[key + "_hbm_bytes_per_launch"] = f * 1024 * 2 + w * 1024
+            traffic[key + "_fetch_size_kib_raw"], traffic[key + "_write_size_kib_raw"] = f, w
         if "SQ_VALU_MFMA_BUSY_CYCLES" in agg[k] and "GRBM_GUI_ACTIVE" in agg[k]:
-            busy = sum(agg[k]["SQ_VALU_MFMA_BUSY_CYCLES"]) / len(agg[k]["SQ_VALU_MFMA_BUSY_CYCLES"])
-            gui = sum(agg[k]["GRBM_GUI_ACTIVE"]) / len(agg[k]["GRBM_GUI_ACTIVE"])
-            extra["mfma_busy_fraction"] = busy / (1024 * gui / 8)      # 1024 SIMDs x cycles per XCD (GRBM_GUI_ACTIVE sums 8 XCDs)
-            extra["mfma_busy_note"] = "SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x GRBM_GUI_ACTIVE / 8)"
-        json.dump({"kernel": k, **extra, "nsgp_project_kernel_hbm_bytes_per_launch": f * 1024 * 2 + w * 1024,
-                   "fetch_size_kib_raw": f, "write_size_kib_raw": w,
-                   "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE passes of `python3 bench.py --steps 10 --warmup 2 --hot-path-only` (tools/profile.sh); FETCH_SIZE x2 per the gfx950 correction"},
-                  open(os.path.join(dst, "traffic.json"), "w"), indent=1)
-        break
+            # 1024 SIMDs x cycles per XCD (GRBM_GUI_ACTIVE sums 8 XCDs)
+            busy = mean(agg[k]["SQ_VALU_MFMA_BUSY_CYCLES"]) / (1024 * mean(agg[k]["GRBM_GUI_ACTIVE"]) / 8)
+            traffic["mfma_busy_fraction" if key == "nsgp_project_kernel" else key + "_mfma_busy_fraction"] = busy
+            traffic["mfma_busy_note"] = "SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x GRBM_GUI_ACTIVE / 8)"
+if len(traffic) > 1:
+    traffic["kernel"] = "nsgp_project_v2_kernel<0> (dense path), nsgp_update_lr_kernel<0> / nsgp_lr_apply_kernel<0> / nsgp_update_kernel<0> (default path)"
+    json.dump(traffic, open(os.path.join(dst, "traffic.json"), "w"), indent=1)
