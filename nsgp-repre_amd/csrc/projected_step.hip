@@ -441,6 +441,14 @@ constexpr int LR_TILE = 32 * LR_TILE_LD;
 
 typedef __attribute__((address_space(3))) f32x4 lf32x4;
 
+// streaming accesses of the low-rank launches (data touched once per launch): the non-temporal hint keeps them from evicting U
+// and T, which every row block re-reads, from L2
+__device__ __forceinline__ f32x4 load4_nt(const float* p) { return __builtin_nontemporal_load((const gf32x4*)p); }
+__device__ __forceinline__ void store4_nt(float* p, f32x4 v) { __builtin_nontemporal_store(v, (gf32x4*)p); }
+__device__ __forceinline__ f32x4 load4_a4_nt(const float* p) {
+    const f32x4_a4 v = __builtin_nontemporal_load((const gf32x4_a4*)p);
+    return f32x4{v[0], v[1], v[2], v[3]};
+}
 __device__ __forceinline__ f32x4 load4_a4(const float* p) {
     const f32x4_a4 v = *(const gf32x4_a4*)p;
     return f32x4{v[0], v[1], v[2], v[3]};
@@ -514,11 +522,11 @@ __global__ __launch_bounds__(256) void nsgp_update_lr_kernel(const TileDev* __re
 #pragma unroll
             for (int it = 0; it < 4; ++it) {
                 const long off = rowbase + it * r8s + 32L * g;
-                const f32x4 g4 = load4_a4(gp + off);
+                const f32x4 g4 = load4_a4_nt(gp + off);
                 float gv[4] = {g4[0], g4[1], g4[2], g4[3]};
                 float pv[4] = {0, 0, 0, 0};
                 if (need_p) {
-                    const f32x4 p4 = *(const gf32x4*)(T.p + off);
+                    const f32x4 p4 = load4_nt(T.p + off);
                     pv[0] = p4[0]; pv[1] = p4[1]; pv[2] = p4[2]; pv[3] = p4[3];
                 }
                 if (OPT == NSGP_OPT_SGD) {
@@ -546,7 +554,7 @@ __global__ __launch_bounds__(256) void nsgp_update_lr_kernel(const TileDev* __re
                     a4[it] = f32x4{uv[0], uv[1], uv[2], uv[3]};
                     *(gf32x4*)(T.u + off) = a4[it];
                 }
-                if (store_g) *(gf32x4_a4*)(gp + off) = f32x4_a4{gv[0], gv[1], gv[2], gv[3]};
+                if (store_g) __builtin_nontemporal_store(f32x4_a4{gv[0], gv[1], gv[2], gv[3]}, (gf32x4_a4*)(gp + off));
             }
 #pragma unroll
             for (int it = 0; it < 4; ++it) lds_put4(tiles + wave * LR_TILE, (r8 + 8 * it) * LR_TILE_LD + 4 * ch, a4[it]);
@@ -644,7 +652,7 @@ __global__ __launch_bounds__(256) void nsgp_lr_apply_kernel(const TileDev* __res
     f32x4 av0[4], pv0[4], av1[4], pv1[4];
     if (has0) {
 #pragma unroll
-        for (int it = 0; it < 4; ++it) { av0[it] = load4_a4(A + off0 + it * r8s); pv0[it] = *(const gf32x4*)(L.p + off0 + it * r8s); }
+        for (int it = 0; it < 4; ++it) { av0[it] = load4_a4_nt(A + off0 + it * r8s); pv0[it] = load4_nt(L.p + off0 + it * r8s); }
     }
     for (int x = threadIdx.x; x < 8 * L.rpad; x += 256) {                               // 32 rows x rpad / 4 pieces, contiguous in memory
         const int row = x / (L.rpad >> 2), c4 = x - row * (L.rpad >> 2);
@@ -652,7 +660,7 @@ __global__ __launch_bounds__(256) void nsgp_lr_apply_kernel(const TileDev* __res
     }
     if (has1) {
 #pragma unroll
-        for (int it = 0; it < 4; ++it) { av1[it] = load4_a4(A + off0 + 128 + it * r8s); pv1[it] = *(const gf32x4*)(L.p + off0 + 128 + it * r8s); }
+        for (int it = 0; it < 4; ++it) { av1[it] = load4_a4_nt(A + off0 + 128 + it * r8s); pv1[it] = load4_nt(L.p + off0 + 128 + it * r8s); }
     }
     __syncthreads();
     float* tile = w_lds + wave * LR_TILE;
@@ -686,7 +694,7 @@ __global__ __launch_bounds__(256) void nsgp_lr_apply_kernel(const TileDev* __res
             f32x4 o;
 #pragma unroll
             for (int e = 0; e < 4; ++e) o[e] = pv[it][e] + c * (scale * av[it][e] - cv[e]);
-            *(gf32x4*)(L.p + off + it * r8s) = o;
+            store4_nt(L.p + off + it * r8s, o);
         }
     };
     if (has0) block(t.n0 + 32 * wave, off0, av0, pv0);
