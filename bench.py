@@ -95,18 +95,30 @@ def _covariance_forward_ms(dev, depth):
         ho, wo = (h + 2 * p - k) // s + 1, (w + 2 * p - k) // s + 1
         ref_flops += 2.0 * ho * wo * (cin * k * k) ** 2
     ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+    from nsgp_repre_amd.runner.nullspace import CovarianceStreams
+    side = CovarianceStreams(4)      # what CovarianceCollector uses by default: layer i on side stream i % 4
 
-    def forward():
-        for n, cin, k, s, p, h, w in layers:
-            covs[n] = ops.cov_accumulate_conv2d(acts[(cin, h, w)], (k, k), (s, s), (p, p), covs.get(n), ws)
-    forward()
-    torch.cuda.synchronize()
-    ts = []
-    for _ in range(3):
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record(); forward(); e1.record(); torch.cuda.synchronize()
-        ts.append(e0.elapsed_time(e1))
-    return sorted(ts)[1], ref_flops, len(layers)
+    def forward(streams):
+        for slot, (n, cin, k, s, p, h, w) in enumerate(layers):
+            x = acts[(cin, h, w)]
+            if streams:
+                nb = ops.cov_workspace_bytes(cin, h, w, (k, k), (s, s), (p, p))
+                covs[n] = side.run(slot, x, lambda wsf, x=x, k=k, s=s, p=p, n=n, nb=nb: ops.cov_accumulate_conv2d(x, (k, k), (s, s), (p, p), covs.get(n), wsf(nb)))
+            else:
+                covs[n] = ops.cov_accumulate_conv2d(x, (k, k), (s, s), (p, p), covs.get(n), ws)
+        if streams:
+            side.join()
+    out = []
+    for streams in (True, False):
+        forward(streams)
+        torch.cuda.synchronize()
+        ts = []
+        for _ in range(3):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(); forward(streams); e1.record(); torch.cuda.synchronize()
+            ts.append(e0.elapsed_time(e1))
+        out.append(sorted(ts)[1])
+    return out[0], out[1], ref_flops, len(layers)
 
 
 def _bank_build(dev, n_classes, n_per_class, seed):
@@ -137,9 +149,9 @@ def once_per_task_units(N, dev):
     """The once-per-task units of work of SURVEY 8d, each timed on its own (never part of `value`)."""
     out = {}
     for depth in (50, 101):
-        ms, ref_flops, n = _covariance_forward_ms(dev, depth)
+        ms, ms1, ref_flops, n = _covariance_forward_ms(dev, depth)
         out[f"covariance_forward_r{depth}"] = {
-            "ms": ms, "hooked_convs": n, "reference_flops": ref_flops, "tflops_by_reference_flops": ref_flops / (ms * 1e-3) / 1e12,
+            "ms": ms, "ms_single_stream": ms1, "streams": 4, "hooked_convs": n, "reference_flops": ref_flops, "tflops_by_reference_flops": ref_flops / (ms * 1e-3) / 1e12,
             "note": "one hooked forward at 800x1344 (fp32 activations); only the upper triangle is computed (half the reference FLOPs), X never materialised"}
     torch.cuda.empty_cache()
     # a5 -> a7: spectra and projectors of all 50 projected layers from SURVEY 8d's seeded covariances (runner:635-662)

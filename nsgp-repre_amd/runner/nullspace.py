@@ -61,22 +61,71 @@ def wire_param_names(optimizer, model: nn.Module) -> None:
             optimizer.param_groups[i]["names"].append(name)
 
 
+class CovarianceStreams:
+    """Side HIP streams for the covariance accumulation of independent layers.
+
+    One hooked forward of R-50-FPN is 61 accumulations of 4-5 launches each, most of them far too small to fill 256 CUs (a
+    1x1 convolution with D = 64 is ONE output tile); on a single stream they run back to back and the forward is bound by
+    the sum of their latencies.  The layers are independent of each other and only READ the activations, so slot ``i`` (a
+    hooked module) is pinned to side stream ``i % n``: its launches are ordered behind the producer of its input (the
+    stream that calls ``run``) and behind the previous accumulations into the same C (same stream, always), and overlap
+    the other layers'.  Every stream owns its workspace.  ``join()`` makes the calling stream wait for all of them --
+    before the covariances are read (all-reduce, save, eigendecomposition).  Results are bitwise what one stream gives."""
+
+    def __init__(self, n_streams: int = 4):
+        self.n = max(1, int(n_streams))
+        self._streams, self._ws = None, None
+
+    def _setup(self, device):
+        if self._streams is None or self._streams[0].device != device:
+            self._streams = [torch.cuda.Stream(device=device) for _ in range(self.n)]
+            self._ws = [None] * self.n
+
+    def workspace(self, k, nbytes, device):
+        w = self._ws[k]
+        if w is None or w.numel() < nbytes or w.device != device:
+            w = self._ws[k] = torch.empty(nbytes, dtype=torch.uint8, device=device)
+        return w
+
+    def run(self, slot: int, x: torch.Tensor, fn):
+        """``fn(workspace_getter)`` on the slot's side stream, ordered behind everything already queued on the current
+        stream; ``x`` (the activation the launches read) is kept alive for that stream."""
+        self._setup(x.device)
+        k = slot % self.n
+        side = self._streams[k]
+        side.wait_stream(torch.cuda.current_stream(x.device))
+        with torch.cuda.stream(side):
+            out = fn(lambda nbytes: self.workspace(k, nbytes, x.device))
+        x.record_stream(side)
+        return out
+
+    def join(self):
+        if self._streams is not None:
+            cur = torch.cuda.current_stream(self._streams[0].device)
+            for s in self._streams:
+                cur.wait_stream(s)
+
+
 class CovarianceCollector:
     """Forward hooks that accumulate ``C_k (+)= X^T X`` per hooked Conv2d / Linear.
 
-    Mirrors ``compute_cov`` + ``update_cov`` (runner:876-934) with three changes of *how*: the
+    Mirrors ``compute_cov`` + ``update_cov`` (runner:876-934) with four changes of *how*: the
     module->name map is built once instead of scanning ``named_modules()`` inside every hook call
-    (runner:893-896), X is never materialised (HIP implicit im2col, see csrc/covariance.hip) and
-    there is no ``empty_cache()`` per call (runner:915).  ``fea_in`` has the reference's layout:
+    (runner:893-896), X is never materialised (HIP implicit im2col, see csrc/covariance.hip),
+    there is no ``empty_cache()`` per call (runner:915), and the accumulations of different layers run on
+    ``n_streams`` side HIP streams (``CovarianceStreams``; 1 = everything on the current stream) -- call ``join()``
+    (``remove()`` does) before reading ``fea_in``.  ``fea_in`` has the reference's layout:
     ``{module_name + '.weight': [D x D] fp32}``."""
 
-    def __init__(self, model: nn.Module, ignore_keys: Sequence[str]):
+    def __init__(self, model: nn.Module, ignore_keys: Sequence[str], n_streams: int = 4):
         self.model = unwrap(model)
         self.ignore_keys = list(ignore_keys)
         self.fea_in: Dict[str, torch.Tensor] = {}
         self._names = {}
+        self._slots = {}
         self._handles = []
         self._workspace = None
+        self._streams = CovarianceStreams(n_streams) if n_streams > 1 else None
 
     def hooked_modules(self):
         # every module that has a `.weight` and is not ignored (runner:723-724); only Conv2d and
@@ -87,10 +136,17 @@ class CovarianceCollector:
     def register(self):
         for n, m in self.hooked_modules():
             self._names[m] = n + ".weight"
+            self._slots[m] = len(self._slots)
             self._handles.append(m.register_forward_hook(self.compute_cov))
         return self
 
+    def join(self):
+        """The current stream waits for every side stream: call before reading ``fea_in``."""
+        if self._streams is not None:
+            self._streams.join()
+
     def remove(self):
+        self.join()
         for h in self._handles:
             h.remove()
         self._handles = []
@@ -111,7 +167,11 @@ class CovarianceCollector:
             x = x.detach().float().contiguous()
             k, s, p = module.kernel_size, module.stride, module.padding
             nbytes = ops.cov_workspace_bytes(x.shape[1], x.shape[2], x.shape[3], k, s, p)
-            self.fea_in[name] = ops.cov_accumulate_conv2d(x, k, s, p, self.fea_in.get(name), self._ws(nbytes, x.device))
+            if self._streams is None or not x.is_cuda:
+                self.fea_in[name] = ops.cov_accumulate_conv2d(x, k, s, p, self.fea_in.get(name), self._ws(nbytes, x.device))
+            else:
+                self.fea_in[name] = self._streams.run(
+                    self._slots[module], x, lambda ws: ops.cov_accumulate_conv2d(x, k, s, p, self.fea_in.get(name), ws(nbytes)))
         return None
 
 

@@ -93,6 +93,30 @@ def test_cal_fea_in_matches_oracle_and_accumulates_previous_task(N, dev):
     assert not any(len(m._forward_hooks) for m in net.modules())   # hooks removed
 
 
+def test_covariance_side_streams_are_bitwise_the_single_stream_result(N, dev):
+    """``CovarianceCollector`` runs the accumulations of different layers on side HIP streams (layer i on stream i % n,
+    ordered behind the producer of its input and behind earlier accumulations into the same C); ``join()`` / ``remove()``
+    order the caller behind them.  Three batches, 1 / 2 / 4 / 8 streams: every covariance bit for bit the same."""
+    from nsgp_repre_amd.runner.nullspace import CovarianceCollector
+    torch.manual_seed(4)
+    net = nn.Sequential(*[nn.Conv2d(c_in, c_out, k, padding=k // 2) for c_in, c_out, k in
+                          ((3, 16, 3), (16, 32, 1), (32, 64, 3), (64, 64, 1), (64, 128, 3), (128, 64, 1), (64, 32, 3), (32, 8, 1))]).to(dev).eval()
+    batches = [torch.randn(2, 3, 40, 56, device=dev) for _ in range(3)]
+    got = {}
+    for n_streams in (1, 2, 4, 8):
+        col = CovarianceCollector(net, [], n_streams=n_streams).register()
+        with torch.no_grad():
+            for b in batches:
+                net(b)
+        col.remove()            # joins the side streams
+        torch.cuda.synchronize()
+        got[n_streams] = {k: v.clone() for k, v in col.fea_in.items()}
+    assert len(got[1]) == 8
+    for n_streams in (2, 4, 8):
+        for k in got[1]:
+            assert torch.equal(got[n_streams][k], got[1][k]), (n_streams, k)
+
+
 def test_covariance_hooks_under_bf16_activations(N, dev):
     """configs[4] ("fp32 covariance / bf16 activations"): when the hooked forward runs under bf16 autocast the hooks see bf16
     inputs.  The covariance stays fp32: each hook widens its input exactly (bf16 -> fp32 is lossless), so the result must equal
