@@ -786,16 +786,18 @@ def test_full_table_low_rank_default_vs_oracle_per_row(N, dev, depth):
 
 def test_low_rank_takes_misaligned_gradient_views_and_every_rank_class(N, dev):
     """Gradients that are views into a flat bucket at 4-byte-aligned offsets (DDP's gradient_as_bucket_view) on the low-rank
-    launches, for one layer of each rank class (rpad = 32, 64, 96, 128) and both optimizer kinds, against the oracle."""
-    ranks = {"backbone.r20.weight": 20, "neck.r33.weight": 33, "backbone.r96.weight": 96, "neck.r128.weight": 128, "backbone.r129.weight": 129}
+    launches, for layers of each rank class (U padded to 32, 64 or 128 columns), SGD (Nesterov) / AdamW / AdamW-AMSGrad, against the oracle; a layer with
+    129 removed directions and one whose row count is not a 32-multiple take the dense GEMM with their head-form projector."""
+    ranks = {"backbone.r20.weight": 20, "neck.r33.weight": 33, "backbone.r96.weight": 96, "neck.r128.weight": 128, "backbone.r129.weight": 129,
+             "neck.rows48.weight": 10}
     shapes = {"backbone.r20.weight": (64, 160), "neck.r33.weight": (96, 32, 3, 3), "backbone.r96.weight": (32, 512, 1, 1),
-              "neck.r128.weight": (160, 384), "backbone.r129.weight": (128, 256), "x.bias": (7,)}
-    for kind in ("sgd", "adamw"):
+              "neck.r128.weight": (160, 384), "backbone.r129.weight": (128, 256), "neck.rows48.weight": (48, 64), "x.bias": (7,)}
+    for kind in ("sgd", "adamw", "adamw_amsgrad"):
         gen = torch.Generator().manual_seed(31)
         init = {n: torch.randn(s, generator=gen) * 0.05 for n, s in shapes.items()}
         params = {n: torch.nn.Parameter(init[n].clone().to(dev)) for n in shapes}
         opt = (N.SGDNSCL(list(params.values()), lr=0.02, momentum=0.9, weight_decay=1e-4, nesterov=True, svd=True) if kind == "sgd"
-               else N.AdamWNSCL(list(params.values()), lr=1e-3, weight_decay=0.05, svd=True))
+               else N.AdamWNSCL(list(params.values()), lr=1e-3, weight_decay=0.05, svd=True, amsgrad=kind.endswith("amsgrad")))
         opt.param_groups[0]["names"] = list(shapes)
         for n, r in ranks.items():
             D = int(np.prod(shapes[n][1:]))
@@ -819,9 +821,9 @@ def test_low_rank_takes_misaligned_gradient_views_and_every_rank_class(N, dev):
                                 lr=0.02, momentum=0.9, weight_decay=1e-4, nesterov=True)
             else:
                 O.adamw_nscl_step(list(shapes), [cpu[n] for n in shapes], [grads[n].clone() for n in shapes], states, tr_cpu,
-                                  lr=1e-3, weight_decay=0.05)
+                                  lr=1e-3, weight_decay=0.05, amsgrad=kind.endswith("amsgrad"))
         torch.cuda.synchronize()
-        assert opt.lowrank_stats()[0] == 4, opt.lowrank_stats()          # r = 129 takes the dense GEMM
+        assert opt.lowrank_stats()[0] == 4, opt.lowrank_stats()          # r = 129 and the 48-row layer (head-form P, not a 32-multiple) take the dense GEMM
         _check(params, cpu, init, kind)
 
 
