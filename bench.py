@@ -7,9 +7,10 @@ K=150 prototype bank), backward, SGDNSCL.step (50 projected layers; the dense fo
 get_eigens-style pipeline (eigh -> elbow -> set_basis), so the step runs the DEFAULT path: head-form projectors applied in the
 low-rank form p += c (u - (u U) U^T), which makes the step HBM-bound.  `value` = whole-job training img/s over all ranks
 (BASELINE's metric); `nsgp_step_ms` = the HIP launches of the projected optimizer step inside that very loop (HIP events recorded
-by the library on the launch stream); `roofline` is the step's dominant kernel (the multi-tensor update launch, HBM-bound) from
-its average duration over the same K timed steps, with the low-rank launches and the dense-GEMM kernel (still what externally
-assigned projectors run on) as blocks beside it.
+by the library on the launch stream around every launch); `roofline` is the step's longest launch -- nsgp_update_lr_kernel, the
+projected layers' elementwise update fused with T = u U, HBM-bound -- from its average duration over the same K timed steps, with
+the other launches of the step as blocks beside it and the dense-GEMM kernel (still what externally assigned projectors run on)
+under `hot_path`.
 
 Multi-GPU: one process per GPU (torchrun); the detector is wrapped in DistributedDataParallel, so the bucketed RCCL all-reduce
 of the 41.5 M fp32 gradients (overlapped with backward) IS inside the timed region for N > 1; the projected step itself is
