@@ -94,11 +94,26 @@ def adam_moments_update(grad: torch.Tensor, p: torch.Tensor, state: dict, *, lr:
     return -step_size * exp_avg / denom
 
 
-def project_update(update: torch.Tensor, P: Optional[torch.Tensor]) -> torch.Tensor:
+class HeadBasis:
+    """A projector given by the r REMOVED directions instead of the dense matrix: ``P = c (I - U U^T)``, ``U = V[:, :r]``
+    (SGD_NSCL.py:270-285 builds the same matrix from the other side, ``V[:, r:] V[:, r:]^T``, ``/ ||P||_F`` for backbone
+    layers; the two are equal for an orthonormal V).  ``project_update`` applies it as ``c (u - (u U) U^T)``, the form the
+    north star names (g <- g - U (U^T g)) and the product's default step runs."""
+
+    def __init__(self, U: torch.Tensor, normalise: bool):
+        self.U = U
+        D = U.shape[0]
+        self.c = 1.0 / float(torch.norm(torch.eye(D, dtype=U.dtype) - U @ U.t())) if normalise else 1.0
+
+
+def project_update(update: torch.Tensor, P) -> torch.Tensor:
     """mmdet/engine/optimizers/SGD_NSCL.py:82-94: right-multiply the final
     update by the projector; 4-D weights are viewed as ``[Cout, Cin*kh*kw]``."""
     if P is None:
         return update
+    if isinstance(P, HeadBasis):
+        u2 = update.reshape(update.size(0), -1)
+        return (P.c * (u2 - torch.mm(torch.mm(u2, P.U), P.U.t()))).view_as(update)
     if update.dim() == 4:
         return torch.mm(update.view(update.size(0), -1), P).view_as(update)
     return torch.mm(update, P)

@@ -389,3 +389,70 @@ def g9_batch(seed=9):
         out.append(dict(gt_bboxes=gt.astype(np.float32), gt_labels=rng.integers(15, 20, g).astype(np.int64),
                         pred_bboxes=p[order], pred_scores=s[order], pred_labels=rng.integers(0, 15, p.shape[0]).astype(np.int64)))
     return out
+
+
+# ------------------------------------------------------------------ G1c: the low-rank step on the REFERENCE's own basis
+# What G1b cannot reach: the default step applies `p += c (u - (u U) U^T)` from the r removed directions U (rank classes rpad = 32 / 64 /
+# 128; layers wider than 256 columns are cut into K ranges whose slabs a reduce launch sums).  The fixture stores the reference's own
+# U = eigen_vector[:, :r] (torch.svd, SGD_NSCL.py:377) for G1b's three layers plus two wide ones whose seeded spectrum puts the elbow in
+# the two upper rank classes, and the reference's step() outputs; a test installs exactly that U (`set_basis`) and compares with nothing
+# added.  Parameters start at zero and gradient rows span six decades, as in G1b.  P itself is not stored (only U [D x r]).
+G1C_STEPS = dict(sgd=2, sgd_nesterov=1, adamw=1)
+G1C_KINDS = ("sgd", "sgd_nesterov", "adamw")
+_G1C = [
+    ("neck.lateral_convs.1.conv.weight", (128, 128, 1, 1), True, None),
+    ("backbone.layer3.0.conv1.weight", (256, 256, 1, 1), True, None),
+    ("neck.fc.weight", (128, 256), True, None),
+    ("neck.wide64.weight", (64, 1152), True, (40, 1.0)),          # elbow 48: rpad 64, 5 K ranges
+    ("backbone.layer4.wide128.weight", (64, 256, 3, 3), True, (90, 1.0)),   # D = 2304, elbow 99: rpad 128, 9 K ranges; backbone -> / ||P||_F
+    ("backbone.layer3.0.bn1.weight", (256,), False, None),
+]
+
+
+def g1c_layers():
+    return [n for n, *_ in _G1C], [s for _, s, *_ in _G1C]
+
+
+def g1c_projected():
+    return [n for n, _, p, _ in _G1C if p]
+
+
+def g1c_params():
+    out = []
+    for i, (_, shp, proj, _) in enumerate(_G1C):
+        rng = np.random.default_rng(170 + i)
+        out.append(np.zeros(shp, np.float32) if proj else (rng.standard_normal(shp) * 0.02).astype(np.float32))
+    return out
+
+
+def g1c_grads(step):
+    out = []
+    for i, (_, shp, proj, _) in enumerate(_G1C):
+        rng = np.random.default_rng(1700 + 37 * step + i)
+        g = rng.standard_normal(shp).astype(np.float32)
+        if proj:    # row r scaled by 10^(-6 (r mod 32) / 31)
+            rows = np.power(10.0, -6.0 * (np.arange(shp[0]) % 32) / 31.0).astype(np.float32)
+            g *= rows.reshape((-1,) + (1,) * (len(shp) - 1))
+        out.append(g)
+    return out
+
+
+def covariance_with_head(D, seed, head, gap, rows_mult=2):
+    """C = X^T X with a flat head of ``head`` strong directions (column scales 1 ... 10^-0.1), a cliff of ``gap`` decades and a
+    tail decaying to 10^-3, rotated by a seeded orthogonal matrix so that the eigenvectors are dense."""
+    rng = np.random.default_rng(seed)
+    X = rng.standard_normal((rows_mult * D, D)).astype(np.float32)
+    scale = np.concatenate([np.logspace(0, -0.1, head), np.logspace(-0.1 - gap, -3, D - head)]).astype(np.float32)
+    X *= scale[None, :]
+    Q, _ = np.linalg.qr(rng.standard_normal((D, D)).astype(np.float32))
+    X = X @ Q.astype(np.float32)
+    return (X.T @ X).astype(np.float32)
+
+
+def g1c_covariances():
+    out = {}
+    for i, (n, shp, proj, head) in enumerate(_G1C):
+        if proj:
+            D = int(np.prod(shp[1:]))
+            out[n] = covariance_like(D, 2700 + i, rows_mult=2) if head is None else covariance_with_head(D, 2700 + i, *head)
+    return out

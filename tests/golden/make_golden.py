@@ -115,6 +115,41 @@ def run_optimizer_aligned(kind):
     save(f"g1b_{kind}.npz", **out)
 
 
+def run_optimizer_lowrank_basis(kind):
+    """G1c: the reference's own removed directions U = eigen_vector[:, :r] (SGD_NSCL.py:377 torch.svd; the mask of :270 is a suffix) and
+    its step() outputs on layers that reach every rank class and the K-range path of the default low-rank step (see inputs.py)."""
+    names, shapes = I.g1c_layers()
+    params = [nn.Parameter(torch.from_numpy(a)) for a in I.g1c_params()]
+    fea_in = {n: torch.from_numpy(c) for n, c in I.g1c_covariances().items()}
+    cls = dict(sgd=ref_sgd.SGDNSCL, sgd_nesterov=ref_sgd.SGDNSCL, adamw=ref_adamw.AdamWNSCL)[kind]
+    opt = cls(params, svd=True, **I.G1_HYPER[kind])
+    opt.param_groups[0]["names"] = list(names)
+    opt.get_eigens(fea_in)
+    opt.get_transforms(offset=I.G1_OFFSET)
+    out = {}
+    for n in names:
+        if n in opt.transforms:
+            key = n.replace(".", "_")
+            mask = opt.adaptive_threshold(opt.eigens[n]["eigen_value"], offset=I.G1_OFFSET)
+            r = int(mask.to(torch.int8).argmax())
+            assert mask[r:].all() and not mask[:r].any()
+            out[f"rank__{key}"] = np.int64(r)
+            out[f"Pnorm__{key}"] = opt.transforms[n].norm().numpy()
+            if kind == "sgd":      # the basis is the optimizer-independent part: stored once
+                out[f"sigma__{key}"] = opt.eigens[n]["eigen_value"].numpy()
+                out[f"U__{key}"] = opt.eigens[n]["eigen_vector"][:, :r].contiguous().numpy()
+    # only the projected parameters after each step are stored (the elementwise state is pinned by G1 / G1b); the second step -- the
+    # momentum recurrence on a non-first step, p != 0 -- for plain SGD only, to keep the fixture small
+    for step in range(I.G1C_STEPS[kind]):
+        for p, g in zip(params, I.g1c_grads(step)):
+            p.grad = torch.from_numpy(g)
+        opt.step()
+        for n, p in zip(names, params):
+            if n in opt.transforms:
+                out[f"p_step{step}__{n.replace('.', '_')}"] = p.detach().numpy().copy()
+    save(f"g1c_{kind}.npz", **out)
+
+
 # ---------------------------------------------------------------- G2 thresholds
 def run_thresholds():
     spectra = I.g2_spectra()
@@ -536,6 +571,10 @@ if __name__ == "__main__":
         for kind in I.G1B_KINDS:
             run_optimizer_aligned(kind)
         sys.exit(0)
+    if sys.argv[1:] == ["g1c"]:        # only the low-rank-basis optimizer fixtures
+        for kind in I.G1C_KINDS:
+            run_optimizer_lowrank_basis(kind)
+        sys.exit(0)
     if sys.argv[1:] == ["g8"]:         # only the RoI-dump and pseudo-label fixtures
         run_roi_dump()
         run_pseudo_labels()
@@ -544,6 +583,8 @@ if __name__ == "__main__":
         run_optimizer(kind)
     for kind in I.G1B_KINDS:
         run_optimizer_aligned(kind)
+    for kind in I.G1C_KINDS:
+        run_optimizer_lowrank_basis(kind)
     run_thresholds()
     run_covariance()
     run_prototypes()

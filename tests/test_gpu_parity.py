@@ -665,7 +665,8 @@ def test_build_projector_head_vs_oracle(N, dev, D, first, norm):
 
 @pytest.mark.parametrize("kind", list(I.G1B_KINDS))
 def test_g1b_default_pipeline_from_covariance_per_row(N, dev, golden_dir, kind):
-    """The DEFAULT path end to end against the reference's own output (G1b, 128-aligned layers): covariance -> ``get_eigens``
+    """EIGENSOLVER-DISTANCE statement (not the kernel gate: that is test_g1c_default_low_rank_launches_on_the_references_basis_per_row,
+    which holds the same launches to the reference's output at 1e-5 given the reference's own basis).  The DEFAULT path end to end against the reference's own output (G1b, 128-aligned layers): covariance -> ``get_eigens``
     (eigh on the GPU) -> elbow -> head-form projector -> low-rank step, next to the reference's literal formula on the same
     optimizer (``low_rank = False``: V_tail V_tail^T and the dense GEMM).  Three statements, first step from p = 0, row by row:
     (i) the two forms of the product agree under THE GATE; (ii) against what the reference's ``step()`` produced with ITS
@@ -709,6 +710,55 @@ def test_g1b_default_pipeline_from_covariance_per_row(N, dev, golden_dir, kind):
         assert _row_rel(got[True][n], got[False][n]) <= REL, (kind, n, "the two forms of the product")           # (i)
         assert d_low <= max(REL, 1.5 * d_dense), (kind, n, d_low, d_dense)                                          # (ii)
         assert d_low <= 5e-5 and d_dense <= 5e-5, (kind, n, d_low, d_dense)                                         # (iii)
+
+
+@pytest.mark.parametrize("polish", [True, False])
+@pytest.mark.parametrize("kind", list(I.G1C_KINDS))
+def test_g1c_default_low_rank_launches_on_the_references_basis_per_row(N, dev, golden_dir, kind, polish):
+    """THE GATE on the DEFAULT step kernels against reference output, given the reference's own basis (kernel parity is
+    judged given identical (U, r)).  G1c stores U = eigen_vector[:, :r] of the reference's torch.svd and what its ``step()`` --
+    ``torch.mm(update, V_tail V_tail^T [/ ||.||_F])``, SGD_NSCL.py:82-94,270-285 -- made of p0 = 0 and gradient rows over six
+    decades, on layers that reach every path of the low-rank launches: r = 21 / 23 / 24 (rpad 32, one K range), r = 48 at D = 1152
+    (rpad 64, 5 K ranges: slabs + nsgp_lr_reduce_kernel), r = 99 at D = 2304 (rpad 128, 9 K ranges; backbone: Frobenius scale).
+    ``set_basis(n, U_ref, r)`` installs exactly that basis; every projected layer must run on nsgp_update_lr_kernel /
+    nsgp_lr_apply_kernel; every output row within 1e-5 of its own maximum, nothing added.  SGD (momentum; Nesterov) and AdamW."""
+    g = np.load(os.path.join(golden_dir, f"g1c_{kind}.npz"))
+    gU = np.load(os.path.join(golden_dir, "g1c_sgd.npz"))
+    names, _ = I.g1c_layers()
+    params = [torch.nn.Parameter(torch.from_numpy(a).to(dev)) for a in I.g1c_params()]
+    opt = _make_opt(N, kind, params)
+    opt.param_groups[0]["names"] = list(names)
+    opt.polish_basis = polish
+    assert opt.low_rank is True
+    for n in I.g1c_projected():
+        r = int(g[f"rank__{_key(n)}"])
+        U = torch.from_numpy(gU[f"U__{_key(n)}"]).to(dev)
+        assert U.shape[1] == r
+        opt.set_basis(n, U, r)
+    worst = {}
+    for step in range(I.G1C_STEPS[kind]):
+        for p, a in zip(params, I.g1c_grads(step)):
+            p.grad = torch.from_numpy(a).to(dev)
+        opt.step()
+        torch.cuda.synchronize()
+        assert opt.lowrank_stats()[0] == len(I.g1c_projected()) == 5 and opt.tile_counts() == (0, 0, 0)
+        for n, p in zip(names, params):
+            if n not in I.g1c_projected():
+                continue
+            ref = torch.from_numpy(g[f"p_step{step}__{_key(n)}"])
+            if step == 0:       # p0 = 0: p IS the projected update -- the gate itself
+                worst[n] = _row_rel(p, ref)
+                assert worst[n] <= REL, (kind, n, worst[n])
+            else:               # p != 0: the fp32 add of the update into p rounds at ulp(p) on both sides
+                assert _rel(p, ref) <= REL, (kind, n, step)
+    out_dir = os.environ.get("NSGP_REPORT_DIR")
+    if out_dir:
+        import json
+        os.makedirs(out_dir, exist_ok=True)
+        json.dump(dict(fixture=f"g1c_{kind}", polish_basis=polish, gate="max_n|ours-ref| <= 1e-5 * max_n|ref| per output row, p0 = 0",
+                       worst_row_rel_vs_reference=worst, ranks={n: int(g[f"rank__{_key(n)}"]) for n in I.g1c_projected()}),
+                  open(os.path.join(out_dir, f"parity_g1c_{kind}_{'polished' if polish else 'raw'}.json"), "w"), indent=1)
+    opt.close()
 
 
 @pytest.mark.parametrize("depth", [50, 101])

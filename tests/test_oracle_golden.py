@@ -118,6 +118,44 @@ def test_g1b_aligned_layers_per_row(golden_dir, kind):
                 np.testing.assert_allclose(st[sk].numpy(), g[f"{sk}__{_key(n)}"], rtol=1e-6, atol=1e-14)
 
 
+@pytest.mark.parametrize("kind", list(I.G1C_KINDS))
+def test_g1c_low_rank_form_on_the_references_basis_per_row(golden_dir, kind):
+    """G1c: the low-rank form c (u - (u U) U^T) with the REFERENCE's own removed directions U = eigen_vector[:, :r] (its torch.svd)
+    reproduces the reference's step() -- which multiplies by the dense V_tail V_tail^T -- within the 1e-5 gate on every output row,
+    in every rank class (r = 21-24, 48, 99), with nothing added to the tolerance.  The spectrum and the rank come out of the
+    oracle's own decomposition as well (rank: exact)."""
+    g = _load(golden_dir, f"g1c_{kind}.npz")
+    gU = _load(golden_dir, "g1c_sgd.npz")
+    names, _ = I.g1c_layers()
+    hp = dict(I.G1_HYPER[kind])
+    fea_in = {n: torch.from_numpy(c) for n, c in I.g1c_covariances().items()}
+    transforms, ranks = {}, {}
+    for n in I.g1c_projected():
+        r = int(g[f"rank__{_key(n)}"])
+        s, _V = O.eigens(fea_in[n])
+        np.testing.assert_array_equal(s.numpy(), gU[f"sigma__{_key(n)}"])
+        mask = O.adaptive_threshold(s, I.G1_OFFSET, "sgd" if kind.startswith("sgd") else "adam")
+        assert int(mask.to(torch.int8).argmax()) == r
+        U = torch.from_numpy(gU[f"U__{_key(n)}"])
+        assert U.shape == (fea_in[n].shape[0], r)
+        transforms[n] = O.HeadBasis(U, "backbone" in n)
+        ranks[n] = r
+    assert sorted(ranks.values()) == [21, 23, 24, 48, 99]        # rank classes 32 / 64 / 128 of the HIP step
+    params = [torch.from_numpy(a) for a in I.g1c_params()]
+    states = [dict() for _ in params]
+    for step in range(I.G1C_STEPS[kind]):
+        grads = [torch.from_numpy(a) for a in I.g1c_grads(step)]
+        STEPPERS[kind](names, params, grads, states, transforms, **hp)
+        for n, p in zip(names, params):
+            if n not in transforms:
+                continue
+            ref = g[f"p_step{step}__{_key(n)}"]
+            if step == 0:       # p0 = 0: p IS the projected update
+                assert _row_rel(p.numpy(), ref) <= 1e-5, (kind, n, _row_rel(p.numpy(), ref))
+            else:               # p != 0: the fp32 add of the update into p rounds at ulp(p) on both sides
+                assert np.abs(p.numpy() - ref).max() <= 1e-5 * np.abs(ref).max(), (kind, n, step)
+
+
 def test_g2_elbow_indices_bit_exact(golden_dir):
     g = _load(golden_dir, "g2_thresholds.npz")
     for si, s in enumerate(I.g2_spectra()):
