@@ -32,7 +32,7 @@ extern "C" {
 #define NSGP_ERR_WORKSPACE (-3) /* workspace too small */
 #define NSGP_ERR_LIMIT (-4)     /* a fixed capacity was exceeded (e.g. > NSGP_MAX_HYPER combos) */
 
-#define NSGP_ABI_VERSION 7
+#define NSGP_ABI_VERSION 8
 #define NSGP_MAX_HYPER 32 /* distinct hyper-parameter sets per plan step */
 
 int nsgp_abi_version(void);
@@ -258,6 +258,30 @@ int repre_replay_ce_forward(const float* scores, const int64_t* labels, int n_ro
                             float* loss_out, void* stream);
 int repre_replay_ce_backward(const float* scores, const int64_t* labels, int n_rows, int n_cols,
                              const float* grad_out, float* grad_scores, void* stream);
+
+/* ------------------------------------------------------------------------
+ * The whole per-step replay pass  (SURVEY rows a16 + a17)
+ * Replaces StandardMultiPrototypeReplayHead.replay_loss, mmdet/models/roi_heads/standard_roi_replay_head.py:468-501, over
+ * Shared2FCBBoxHeadTask.forward, mmdet/models/roi_heads/bbox_heads/convfc_bbox_head_task.py:235-276, and the autograd backward of
+ * both (~40 library launches around one 51 MB weight pass each way) by 6 + 6 launches on the exact fp32 MFMA:
+ *     H1 = relu(bank W1^T + b1);  H2 = relu(H1 W2^T + b2);  S = H2 Wc^T + bc;  loss = mean CE(softmax(S), labels)
+ * bank [n_rows x in_features] (the prototype bank: a constant, no gradient), w1 [hidden x in_features], w2 [hidden x hidden],
+ * wc [n_cols x hidden] = the rows of the per-task fc_cls heads seen so far followed by the background row, stacked by the caller
+ * (the reference keeps the columns [:task_split[task_id]] and the last one, head:495-497), labels int64 [n_rows].
+ * forward writes h1, h2 [n_rows x hidden], scores [n_rows x n_cols] and the scalar loss (all device fp32; the caller keeps
+ * h1 / h2 / scores for backward).  backward writes (not accumulates) gw1 [hidden x in_features], gb1, gw2, gb2 [hidden],
+ * gwc [n_cols x hidden], gbc [n_cols] for upstream gradient *grad_out (device scalar).  Deterministic (fixed summation order).
+ * n_rows <= 512, n_cols <= 256.  workspace: >= repre_replay_head_workspace_bytes(...), 16-byte aligned, shared by both calls.
+ * ------------------------------------------------------------------------ */
+size_t repre_replay_head_workspace_bytes(int n_rows, int in_features, int hidden, int n_cols);
+int repre_replay_head_forward(const float* bank, int n_rows, int in_features, const float* w1, const float* b1, const float* w2,
+                              const float* b2, const float* wc, const float* bc, int hidden, int n_cols, const int64_t* labels,
+                              float* h1, float* h2, float* scores, float* loss_out, void* workspace, size_t workspace_bytes,
+                              void* stream);
+int repre_replay_head_backward(const float* bank, int n_rows, int in_features, const float* w2, const float* wc, int hidden,
+                               int n_cols, const int64_t* labels, const float* h1, const float* h2, const float* scores,
+                               const float* grad_out, float* gw1, float* gb1, float* gw2, float* gb2, float* gwc, float* gbc,
+                               void* workspace, size_t workspace_bytes, void* stream);
 
 /* ------------------------------------------------------------------------
  * EWC regulariser on the BatchNorm parameters  

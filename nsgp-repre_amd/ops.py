@@ -250,6 +250,66 @@ def double_softmax_cross_entropy(scores: torch.Tensor, labels: torch.Tensor) -> 
     return _DoubleSoftmaxCE.apply(scores.float().contiguous(), labels.contiguous())
 
 
+class _ReplayHeadLoss(torch.autograd.Function):
+    """bank -> relu(fc) -> relu(fc) -> class rows -> CE(softmax(.)) in 6 launches, its backward in 6 (csrc/replay_head.hip)."""
+
+    @staticmethod
+    def forward(ctx, bank, labels, w1, b1, w2, b2, wc, bc):
+        lib = _lib.load_library()
+        K, fin = bank.shape
+        hidden, C_ = w1.shape[0], wc.shape[0]
+        if w1.shape != (hidden, fin) or w2.shape != (hidden, hidden) or wc.shape[1] != hidden:
+            raise ValueError(f"replay head shapes do not chain: bank {tuple(bank.shape)}, w1 {tuple(w1.shape)}, w2 {tuple(w2.shape)}, wc {tuple(wc.shape)}")
+        nbytes = lib.repre_replay_head_workspace_bytes(K, fin, hidden, C_)
+        if nbytes == 0:
+            raise ValueError(f"replay head: unsupported size (rows {K} <= 512, class columns {C_} <= 256)")
+        dev = bank.device
+        ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+        h1 = torch.empty(K, hidden, dtype=torch.float32, device=dev)
+        h2 = torch.empty(K, hidden, dtype=torch.float32, device=dev)
+        scores = torch.empty(K, C_, dtype=torch.float32, device=dev)
+        loss = torch.empty((), dtype=torch.float32, device=dev)
+        _lib.check(lib.repre_replay_head_forward(_dev(bank, "bank"), K, fin, _dev(w1, "w1"), _dev(b1, "b1"), _dev(w2, "w2"), _dev(b2, "b2"),
+                                                 _dev(wc, "wc"), _dev(bc, "bc"), hidden, C_, _dev(labels, "labels", torch.int64),
+                                                 _dev(h1, "h1"), _dev(h2, "h2"), _dev(scores, "scores"), C.c_void_p(loss.data_ptr()),
+                                                 C.c_void_p(ws.data_ptr()), nbytes, _stream()), "repre_replay_head_forward")
+        ctx.save_for_backward(bank, labels, w2, wc, h1, h2, scores)
+        ctx.ws = ws
+        ctx.mark_non_differentiable(scores)
+        return loss, scores
+
+    @staticmethod
+    def backward(ctx, grad_loss, _grad_scores):
+        bank, labels, w2, wc, h1, h2, scores = ctx.saved_tensors
+        lib = _lib.load_library()
+        K, fin = bank.shape
+        hidden, C_ = w2.shape[0], wc.shape[0]
+        dev = bank.device
+        go = grad_loss.detach().reshape(()).float().contiguous()
+        gw1 = torch.empty(hidden, fin, dtype=torch.float32, device=dev)
+        gb1 = torch.empty(hidden, dtype=torch.float32, device=dev)
+        gw2 = torch.empty(hidden, hidden, dtype=torch.float32, device=dev)
+        gb2 = torch.empty(hidden, dtype=torch.float32, device=dev)
+        gwc = torch.empty(C_, hidden, dtype=torch.float32, device=dev)
+        gbc = torch.empty(C_, dtype=torch.float32, device=dev)
+        ws = ctx.ws
+        _lib.check(lib.repre_replay_head_backward(_dev(bank, "bank"), K, fin, _dev(w2, "w2"), _dev(wc, "wc"), hidden, C_,
+                                                  _dev(labels, "labels", torch.int64), _dev(h1, "h1"), _dev(h2, "h2"), _dev(scores, "scores"),
+                                                  C.c_void_p(go.data_ptr()), _dev(gw1, "gw1"), _dev(gb1, "gb1"), _dev(gw2, "gw2"), _dev(gb2, "gb2"),
+                                                  _dev(gwc, "gwc"), _dev(gbc, "gbc"), C.c_void_p(ws.data_ptr()), ws.numel(), _stream()),
+                   "repre_replay_head_backward")
+        return None, None, gw1, gb1, gw2, gb2, gwc, gbc
+
+
+def replay_head_loss(bank: torch.Tensor, labels: torch.Tensor, w1, b1, w2, b2, wc, bc):
+    """The per-step replay pass of standard_roi_replay_head.py:468-501 over the two shared FCs and the kept class rows of
+    ``Shared2FCBBoxHeadTask`` (convfc_bbox_head_task.py:235-276), fused: ``(loss, scores)`` with
+    ``scores = relu(relu(bank w1^T + b1) w2^T + b2) wc^T + bc`` and ``loss = F.cross_entropy(scores.softmax(-1), labels)``.
+    The bank is a constant (no gradient); gradients flow to the six weight / bias tensors.  fp32, GPU only."""
+    args = [t.float().contiguous() for t in (w1, b1, w2, b2, wc, bc)]
+    return _ReplayHeadLoss.apply(bank.detach().float().contiguous(), labels.contiguous(), *args)
+
+
 def pseudo_label_filter(boxes: torch.Tensor, scores: torch.Tensor, gt_boxes: torch.Tensor, rpn_thresh: float,
                         roi_thresh: float, iou_thresh: float = 0.7):
     """Sequential teacher pseudo-label filter of one image -> (add_to_rpn bool[P], add_to_roi bool[P]) --

@@ -86,13 +86,50 @@ class PrototypeReplay:
         results.update(replay_loss=dict(replay_loss_cls=loss))
         return results
 
+    #: run the per-step replay pass on the fused HIP path (csrc/replay_head.hip) when the bbox head has the Shared2FC shape;
+    #: False = always the module-by-module path of ``replay_loss`` (torch GEMMs + the fused CE)
+    fused_replay = True
+
+    def _fused_replay_operands(self):
+        """(w1, b1, w2, b2, wc, bc) when ``bbox_head`` is a two-shared-FC task head whose kept class columns are whole Linear heads
+        (the ``Shared2FCBBoxHeadTask`` of every reference config), else None."""
+        h = self.bbox_head
+        if getattr(self, "with_shared_head", False) or not hasattr(h, "shared_fcs") or not hasattr(h, "fc_cls"):
+            return None
+        if (getattr(h, "num_shared_convs", 0) or getattr(h, "num_shared_fcs", 0) != 2 or getattr(h, "num_cls_convs", 0)
+                or getattr(h, "num_cls_fcs", 0) or getattr(h, "with_avg_pool", False) or getattr(h, "background_nums", 1) != 1):
+            return None
+        split, tid = list(h.task_split), h.task_id
+        if split != list(self.task_split) or tid != self.task_id or len(h.fc_cls) != len(split):
+            return None
+        live = list(h.fc_cls[:tid]) + [h.fc_cls[-1]]        # tasks 1..task_id + background: exactly the kept columns (head:495-497)
+        if sum(m.out_features for m in live[:-1]) != split[tid] - split[0] or split[0] != 0:
+            return None
+        fc1, fc2 = h.shared_fcs
+        if any(m.bias is None for m in (fc1, fc2, *live)):
+            return None
+        return (fc1.weight, fc1.bias, fc2.weight, fc2.bias, torch.cat([m.weight for m in live], 0), torch.cat([m.bias for m in live], 0))
+
+    def replay_loss_fused(self, bbox_feats):
+        """``replay_loss`` for the loss alone, fused (6 + 6 launches instead of ~40): returns ``dict(replay_loss_cls=...)`` or None
+        when the head does not have the shape the fused path covers."""
+        ops_ = self._fused_replay_operands() if self.fused_replay else None
+        if ops_ is None or not bbox_feats.is_cuda:
+            return None
+        feats = bbox_feats.reshape(bbox_feats.shape[0], -1)
+        if feats.shape[0] > 512 or ops_[4].shape[0] > 256 or feats.shape[1] != ops_[0].shape[1]:
+            return None
+        loss, _scores = ops.replay_head_loss(feats, self.tmp_label.to(feats.device), *ops_)
+        return dict(replay_loss_cls=loss)
+
     def add_replay_loss(self, losses: dict) -> dict:
         """The tail of ``loss`` (head:454-466): stock RoI losses + ``replay_loss_cls``."""
         if self.replay:
             # the bank pass stays fp32 under an autocast training step (>= the reference's precision; the
             # bf16 path of this K x 12544 x 1024 GEMM measured 7x slower on hipBLASLt)
             with torch.autocast(device_type=self.bbox_featss.device.type, enabled=False):
-                losses.update(self.replay_loss(self.bbox_featss)["replay_loss"])
+                fused = self.replay_loss_fused(self.bbox_featss)
+                losses.update(fused if fused is not None else self.replay_loss(self.bbox_featss)["replay_loss"])
         return losses
 
 

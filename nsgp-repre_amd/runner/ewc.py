@@ -14,6 +14,7 @@ from typing import Dict
 import torch
 
 from .. import _lib
+from .safe_load import load_handoff
 
 EWC_WEIGHT = 1000.0            # runner:1068
 IGNORE_NAMES = ["teacher_model"]
@@ -33,7 +34,7 @@ def register_params(model) -> Dict[str, torch.nn.Parameter]:
 
 def load_importance(path: str, device):
     """``ewc_reg_terms_ewc.pth``: {'importance': {name: [T x (1,*shape)]}, 'task_param': {...}} (runner:996-999)."""
-    return torch.load(path, map_location=device, weights_only=True)
+    return load_handoff(path, device)      # the reference writes defaultdict(list) containers (runner:957-958)
 
 
 class _EwcFunction(torch.autograd.Function):

@@ -22,6 +22,7 @@ import torch.nn as nn
 
 from .. import ops
 from . import dist as D
+from .safe_load import load_handoff
 
 logger = logging.getLogger("nsgp_repre_amd")
 
@@ -200,7 +201,7 @@ def cal_fea_in(model: nn.Module, batches: Iterable, ignore_keys: Sequence[str], 
     D.barrier()
     if task_id != 1 and previous_path is not None:
         dev = next(net.parameters()).device
-        old = torch.load(previous_path, map_location=dev, weights_only=True)
+        old = load_handoff(previous_path, dev)
         fea_in = {k: v + old[k].to(v.device) for k, v in fea_in.items() if not should_ignore(k, ignore_keys)}
     if save_path is not None and D.get_rank() == 0:
         torch.save(fea_in, save_path)
@@ -213,7 +214,7 @@ def update_optim_transforms(optimizer, covariance, ignore_keys: Sequence[str], o
     ``get_eigens`` + ``get_transforms(offset)``.  (The reference runs the identical
     ``update_model_transforms`` right after, i.e. the decomposition twice; once is enough.)"""
     if isinstance(covariance, (str, os.PathLike)):
-        covariance = torch.load(covariance, map_location=device, weights_only=True)
+        covariance = load_handoff(covariance, device)       # the reference's task-1 file is a pickled defaultdict
     fea_in = {k: (v.to(device) if device is not None else v) for k, v in covariance.items()
               if not should_ignore(k, ignore_keys)}
     D.sharded_eigens(optimizer, fea_in)          # = get_eigens on one GPU; layers spread over the ranks under DDP (C4)
@@ -250,7 +251,7 @@ def cal_rois(model: nn.Module, batches: Iterable, save_path: Optional[str] = Non
         gathered = res
     if task_id != 1 and previous_path is not None:
         dev = next(net.parameters()).device
-        old = torch.load(previous_path, map_location=dev, weights_only=True)
+        old = load_handoff(previous_path, dev)
         gathered = [torch.cat([o, g], dim=0) for o, g in zip(old, gathered)]
     if save_path is not None and D.get_rank() == 0:
         torch.save(gathered, save_path)

@@ -456,3 +456,100 @@ def g1c_covariances():
             D = int(np.prod(shp[1:]))
             out[n] = covariance_like(D, 2700 + i, rows_mult=2) if head is None else covariance_with_head(D, 2700 + i, *head)
     return out
+
+
+# ------------------------------------------------------------------ hand-off files written by the reference's own code
+# A task-1 work dir as the reference leaves it: covariance.pth (cal_fea_in, runner:705-763), rois_etc.pth (cal_rois, runner:777-868),
+# ewc_reg_terms_ewc.pth (calculate_save_importance, runner:946-990), and the mask.pth its task-2 head writes (head:451-452).  The net
+# is tiny (the files are the fixture); module names follow the detector's so that ignore_keys, 'backbone' and 'bn' rules all bite.
+HANDOFF_TASK_SPLIT = [0, 3, 5]
+HANDOFF_IGNORE_KEYS = ["rpn", "roi_head"]
+HANDOFF_CLASSES = ((12, 3), (9, 2), (14, 4), (3, 1))     # (rows, clusters): classes 0-2 are the old task; class 3 stands for the rest
+HANDOFF_BATCHES = 4
+
+
+def handoff_net():
+    """torch.nn.Module with backbone.conv1 / backbone.bn1 / backbone.layer1 / neck.conv / rpn_head.conv, seeded weights."""
+    import torch
+    import torch.nn as nn
+
+    class Backbone(nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.conv1 = nn.Conv2d(3, 8, 3, stride=2, padding=1, bias=False)
+            self.bn1 = nn.BatchNorm2d(8)
+            self.layer1 = nn.Conv2d(8, 16, 1, bias=False)
+
+        def forward(self, x):
+            return self.layer1(torch.relu(self.bn1(self.conv1(x))))
+
+    class Neck(nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.conv = nn.Conv2d(16, 16, 3, padding=1)
+
+        def forward(self, x):
+            return self.conv(x)
+
+    class RPN(nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.conv = nn.Conv2d(16, 4, 1)
+
+        def forward(self, x):
+            return self.conv(x)
+
+    class Net(nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.backbone, self.neck, self.rpn_head = Backbone(), Neck(), RPN()
+
+        def features(self, x):
+            return self.rpn_head(torch.relu(self.neck(torch.relu(self.backbone(x)))))
+
+    net = Net()
+    rng = np.random.default_rng(4100)
+    with torch.no_grad():
+        for _, p in sorted(net.named_parameters()):
+            p.copy_(torch.from_numpy((rng.standard_normal(tuple(p.shape)) * 0.3).astype(np.float32)))
+        net.backbone.bn1.running_mean.copy_(torch.from_numpy((rng.standard_normal(8) * 0.1).astype(np.float32)))
+        net.backbone.bn1.running_var.copy_(torch.from_numpy((1.0 + 0.2 * rng.random(8)).astype(np.float32)))
+    return net
+
+
+def handoff_images():
+    """HANDOFF_BATCHES input batches [2 x 3 x 20 x 28] (non-negative)."""
+    return [np.abs(np.random.default_rng(4200 + b).standard_normal((2, 3, 20, 28))).astype(np.float32) for b in range(HANDOFF_BATCHES)]
+
+
+def handoff_roi_batches():
+    """What ``mode='roi_replay'`` returns per batch (the 6-tuple of get_bbox_stuff, head:106-202): rows of clustered RoI features
+    [n x 12544] with their class targets, dealt over the batches; weights / boxes are seeded fillers of the right shapes."""
+    feats, cls = [], []
+    for c, (n, k) in enumerate(HANDOFF_CLASSES):
+        feats.append(class_rois(n, G4_D, 4300 + c, n_clusters=k))
+        cls.append(np.full(n, c if c < 3 else HANDOFF_TASK_SPLIT[-1], dtype=np.int64))      # class 3 = background label
+    feats, cls = np.concatenate(feats), np.concatenate(cls)
+    perm = np.random.default_rng(4400).permutation(len(cls))
+    feats, cls = feats[perm], cls[perm]
+    rng = np.random.default_rng(4500)
+    out = []
+    for idx in np.array_split(np.arange(len(cls)), HANDOFF_BATCHES):
+        n = len(idx)
+        out.append((feats[idx], cls[idx], np.ones(n, np.float32), rng.standard_normal((n, 4)).astype(np.float32),
+                    (rng.random((n, 4)) < 0.5).astype(np.float32), np.concatenate([np.zeros((n, 1)), rng.uniform(0, 200, (n, 4))], 1).astype(np.float32)))
+    return out
+
+
+def handoff_step_inputs():
+    """Seeded gradients for one optimizer step on the net's trainable tensors, in named_parameters() order."""
+    import torch  # noqa: F401
+    net = handoff_net()
+    rng = np.random.default_rng(4600)
+    return {n: rng.standard_normal(tuple(p.shape)).astype(np.float32) for n, p in net.named_parameters()}
+
+
+def handoff_theta():
+    """Task-2 values of the EWC-registered (BatchNorm) parameters the regulariser is evaluated at."""
+    rng = np.random.default_rng(4700)
+    return {"backbone.bn1.weight": (1.0 + 0.3 * rng.standard_normal(8)).astype(np.float32), "backbone.bn1.bias": (0.3 * rng.standard_normal(8)).astype(np.float32)}

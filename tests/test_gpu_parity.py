@@ -721,7 +721,9 @@ def test_g1c_default_low_rank_launches_on_the_references_basis_per_row(N, dev, g
     decades, on layers that reach every path of the low-rank launches: r = 21 / 23 / 24 (rpad 32, one K range), r = 48 at D = 1152
     (rpad 64, 5 K ranges: slabs + nsgp_lr_reduce_kernel), r = 99 at D = 2304 (rpad 128, 9 K ranges; backbone: Frobenius scale).
     ``set_basis(n, U_ref, r)`` installs exactly that basis; every projected layer must run on nsgp_update_lr_kernel /
-    nsgp_lr_apply_kernel; every output row within 1e-5 of its own maximum, nothing added.  SGD (momentum; Nesterov) and AdamW."""
+    nsgp_lr_apply_kernel; every output row within 1e-5 of its own maximum, nothing added -- except that for the two backbone
+    layers the reference's inexact fp32 CPU ``torch.norm`` (one scalar per layer, see below) is taken out first.
+    SGD (momentum; Nesterov) and AdamW."""
     g = np.load(os.path.join(golden_dir, f"g1c_{kind}.npz"))
     gU = np.load(os.path.join(golden_dir, "g1c_sgd.npz"))
     names, _ = I.g1c_layers()
@@ -735,7 +737,7 @@ def test_g1c_default_low_rank_launches_on_the_references_basis_per_row(N, dev, g
         U = torch.from_numpy(gU[f"U__{_key(n)}"]).to(dev)
         assert U.shape[1] == r
         opt.set_basis(n, U, r)
-    worst = {}
+    worst, scales = {}, {}
     for step in range(I.G1C_STEPS[kind]):
         for p, a in zip(params, I.g1c_grads(step)):
             p.grad = torch.from_numpy(a).to(dev)
@@ -746,17 +748,32 @@ def test_g1c_default_low_rank_launches_on_the_references_basis_per_row(N, dev, g
             if n not in I.g1c_projected():
                 continue
             ref = torch.from_numpy(g[f"p_step{step}__{_key(n)}"])
+            s = 1.0
+            if "backbone" in n:
+                # The Frobenius scale.  The reference divides by ITS fp32 `torch.norm(transform)` (SGD_NSCL.py:282-283); on the CPU
+                # that reduction keeps one fp32 vector accumulator over all D^2 squares and drops the small off-diagonal ones: for
+                # this D = 2304 projector it returns 46.9290 where ||P||_F = sqrt(D - r) = 46.9574 (fixture: refnorm / refnorm64),
+                # 6.05e-4 low -- a uniform factor on the layer's update, which the reference's own GPU path (a tree reduction) does
+                # not share.  The product uses the correctly rounded norm (fp64 accumulation, checked here against sqrt(D - r));
+                # the row-wise gate is then held on the update with that ONE scalar per layer taken out.
+                D, r = ref[0].numel(), int(g[f"rank__{_key(n)}"])
+                ours, theirs = float(opt._basis[n]["norm"]), float(g[f"refnorm__{_key(n)}"])
+                assert abs(ours / (D - r) ** 0.5 - 1.0) <= 2e-6, (n, ours, (D - r) ** 0.5)
+                assert abs(float(g[f"refnorm64__{_key(n)}"]) / (D - r) ** 0.5 - 1.0) <= 2e-6
+                s = ours / theirs
+                scales[n] = s
+                assert abs(s - 1.0) <= 1e-3, (n, s)
             if step == 0:       # p0 = 0: p IS the projected update -- the gate itself
-                worst[n] = _row_rel(p, ref)
+                worst[n] = _row_rel(p.detach() * s, ref)
                 assert worst[n] <= REL, (kind, n, worst[n])
             else:               # p != 0: the fp32 add of the update into p rounds at ulp(p) on both sides
-                assert _rel(p, ref) <= REL, (kind, n, step)
+                assert _rel(p.detach() * s, ref) <= REL, (kind, n, step)
     out_dir = os.environ.get("NSGP_REPORT_DIR")
     if out_dir:
         import json
         os.makedirs(out_dir, exist_ok=True)
         json.dump(dict(fixture=f"g1c_{kind}", polish_basis=polish, gate="max_n|ours-ref| <= 1e-5 * max_n|ref| per output row, p0 = 0",
-                       worst_row_rel_vs_reference=worst, ranks={n: int(g[f"rank__{_key(n)}"]) for n in I.g1c_projected()}),
+                       worst_row_rel_vs_reference=worst, frobenius_norm_ours_over_reference_cpu_fp32=scales, ranks={n: int(g[f"rank__{_key(n)}"]) for n in I.g1c_projected()}),
                   open(os.path.join(out_dir, f"parity_g1c_{kind}_{'polished' if polish else 'raw'}.json"), "w"), indent=1)
     opt.close()
 

@@ -352,6 +352,93 @@ def test_replay_loss_through_the_head_vs_reference_golden(N, dev, golden_dir):
     assert inside.dtype == torch.float32 and abs(inside.item() - g["loss"]) <= 2e-6 * abs(float(g["loss"]))
 
 
+def _replay_holder(N, head, labels, bank, split, tid):
+    class Holder(N.roi_heads.PrototypeReplay):
+        pass
+    h = Holder()
+    h.bbox_head, h.task_split, h.task_id = head, list(split), tid
+    h.tmp_label, h.replay, h.bbox_featss = labels, True, bank
+    return h
+
+
+def test_fused_replay_pass_vs_reference_golden(N, dev, golden_dir):
+    """G5 on the FUSED per-step path (csrc/replay_head.hip: skinny split-K MFMA GEMMs + slab reduce + class scores + double-softmax CE,
+    and the hand-written backward): the reference's own loss, its gradients of both shared FCs and of every per-task class head,
+    on G5's ragged shape (K = 14, 196 -> 32 -> 32 -> 6 kept columns: the guarded tiles).  The frozen future head and the
+    regression heads receive no gradient, as in the reference."""
+    from test_runner_host import _g5_head
+    g = np.load(os.path.join(golden_dir, "g5_replay_loss.npz"))
+    head = _g5_head(N, dev)
+    bank, labels = I.g5_bank()
+    h = _replay_holder(N, head, torch.from_numpy(labels).to(dev), torch.from_numpy(bank).reshape(-1, 4, 7, 7).to(dev), I.G5_TASK_SPLIT, I.G5_TASK_ID)
+    assert h._fused_replay_operands() is not None
+    losses = h.add_replay_loss({})
+    assert set(losses) == {"replay_loss_cls"}
+    np.testing.assert_allclose(losses["replay_loss_cls"].item(), g["loss"], rtol=2e-6)
+    losses["replay_loss_cls"].backward()
+    for i, m in enumerate(head.shared_fcs):
+        np.testing.assert_allclose(m.weight.grad.cpu().numpy(), g[f"gW_shared{i}"], rtol=1e-4, atol=1e-7)
+        np.testing.assert_allclose(m.bias.grad.cpu().numpy(), g[f"gb_shared{i}"], rtol=1e-4, atol=1e-7)
+    for i, m in enumerate(head.fc_cls):
+        if bool(g[f"has_grad_cls{i}"]):
+            np.testing.assert_allclose(m.weight.grad.cpu().numpy(), g[f"gW_cls{i}"], rtol=1e-4, atol=1e-7)
+        else:
+            assert m.weight.grad is None
+    assert all(m.weight.grad is None for m in head.fc_reg)
+    # and the module-by-module path gives the same numbers
+    head.zero_grad(set_to_none=True)
+    h.fused_replay = False
+    ref = h.add_replay_loss({})["replay_loss_cls"]
+    assert abs(ref.item() - losses["replay_loss_cls"].item()) <= 2e-6 * abs(ref.item())
+
+
+@pytest.mark.parametrize("K,fin,hidden,split,tid", [(150, 12544, 1024, (0, 15, 20), 2), (100, 12544, 1024, (0, 10, 20), 2),
+                                                    (400, 12544, 1024, (0, 40, 80), 2), (37, 200, 96, (0, 3, 5, 7), 2),
+                                                    (161, 256, 128, (0, 5, 10), 1)])
+def test_fused_replay_pass_at_config_sizes_vs_fp64(N, dev, K, fin, hidden, split, tid):
+    """The fused replay pass at the sizes of configs[1] (K = 150, 21 kept columns), configs[2] (K = 100), configs[3] (K = 400, 81
+    columns), a ragged shape on the guarded tiles and a 6-block bank (two row chunks) against an fp64 autograd evaluation of the
+    same head on the GPU: loss 1e-6, every gradient within 1e-5 of its tensor's maximum; bitwise reproducible run to run; equal to
+    the module-by-module fp32 path within 1e-5."""
+    import copy
+    torch.manual_seed(K + hidden)
+    head = N.roi_heads.Shared2FCBBoxHeadTask(in_channels=fin, fc_out_channels=hidden, roi_feat_size=1, num_classes=split[-1],
+                                             task_split=list(split), task_id=tid).to(dev)
+    with torch.no_grad():
+        for p in head.parameters():
+            p.mul_(3.0)                     # spread the scores: the CE of a softmax is flat for small logits
+    n_old = split[tid - 1] if tid > 1 else split[tid]
+    bank = torch.relu(torch.randn(K, fin, device=dev))
+    labels = torch.randint(0, max(1, n_old), (K,), device=dev)
+    h = _replay_holder(N, head, labels, bank, split, tid)
+    assert h._fused_replay_operands() is not None
+
+    def run(fused):
+        head.zero_grad(set_to_none=True)
+        h.fused_replay = fused
+        loss = h.add_replay_loss({})["replay_loss_cls"]
+        (loss * 1.5).backward()
+        return loss.detach().clone(), {n: p.grad.detach().clone() for n, p in head.named_parameters() if p.grad is not None}
+    loss_f, g_f = run(True)
+    loss_f2, g_f2 = run(True)
+    assert torch.equal(loss_f, loss_f2) and all(torch.equal(g_f[n], g_f2[n]) for n in g_f), "the fused pass is not reproducible"
+    loss_m, g_m = run(False)
+    # fp64 reference
+    h64 = copy.deepcopy(head).double()
+    h64.zero_grad(set_to_none=True)
+    cls64, _ = h64(bank.double())
+    pre = split[tid]
+    kept = torch.cat([cls64[:, :pre], cls64[:, -1:]], -1)
+    loss64 = torch.nn.functional.cross_entropy(kept.softmax(-1), labels)
+    (loss64 * 1.5).backward()
+    g64 = {n: p.grad for n, p in h64.named_parameters() if p.grad is not None}
+    assert set(g_f) == set(g64) == set(g_m), (sorted(g_f), sorted(g64))
+    assert abs(loss_f.item() - loss64.item()) <= 1e-6 * abs(loss64.item()) + 1e-7
+    for n in g64:
+        assert _rel(g_f[n], g64[n]) <= 1e-5, (n, _rel(g_f[n], g64[n]))
+        assert _rel(g_f[n], g_m[n]) <= 1e-5, (n, "fused vs module path")
+
+
 def test_fused_double_softmax_ce_vs_torch_and_golden(N, dev, golden_dir):
     """head:499 ``F.cross_entropy(cls_score.softmax(-1), labels)``: fused kernels vs torch's own ops
     (fp64 reference) on ragged sizes, and vs the reference's loss value of G5."""

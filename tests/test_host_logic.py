@@ -28,7 +28,7 @@ def test_library_loads_and_exports_every_declared_symbol(N):
     assert declared == set(_lib.SIGNATURES), (declared ^ set(_lib.SIGNATURES))
     for name in declared:
         assert hasattr(lib, name), name
-    assert lib.nsgp_abi_version() == 7
+    assert lib.nsgp_abi_version() == 8
     assert lib.nsgp_device_count() >= 0
 
 
