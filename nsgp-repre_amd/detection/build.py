@@ -41,28 +41,8 @@ def synthetic_batch(batch_size, classes, device, height=800, width=1344, seed=0,
 
 
 def relocate_segment_final_weights(model, max_moves: int = 64) -> int:
-    """Guard of the stand-alone harness against a stock MIOpen defect (profiles/README.md, incident analysis;
-    tools/miopen_overread_repro.py): MIOpen's backward-data kernel of a 1x1 convolution reads past the end of its weight tensor,
-    which is a GPU memory access fault when the caching allocator has placed that weight as the LAST block of a full segment with
-    unmapped address space behind it.  Every convolution weight of ``model`` that ends exactly where its segment ends (and no other
-    segment begins) is moved to a fresh allocation; the old block stays referenced by the model (``_segment_end_pads``) so the next
-    weight cannot land there.  Returns how many weights were moved.  A no-op on the CPU; costs one memory snapshot."""
-    params = [m.weight for m in model.modules() if isinstance(m, torch.nn.Conv2d) and m.weight.is_cuda]
-    if not params:
-        return 0
-    pads = getattr(model, "_segment_end_pads", [])
-    moved = 0
-    for _ in range(max_moves):
-        segs = [(s["address"], s["address"] + s["total_size"]) for s in torch.cuda.memory_snapshot()]
-        starts = {a for a, _ in segs}
-        ends = {e for _, e in segs}
-        hit = [p for p in params if (p.data_ptr() + p.numel() * p.element_size()) in ends
-               and (p.data_ptr() + p.numel() * p.element_size()) not in starts]
-        if not hit:
-            break
-        for p in hit:
-            pads.append(p.data)                 # keeps the segment-final block occupied
-            p.data = p.data.clone()
-            moved += 1
-    model._segment_end_pads = pads
-    return moved
+    """The stand-alone harness's name for ``runner.nullspace.guard_conv_weights`` (a stock MIOpen 1x1 backward-data kernel reads past
+    its weight tensor; see there).  The runner faces call the guard themselves; harnesses that drive a detector without a runner
+    (bench.py, tools/) call it after ``.to(device)``."""
+    from ..runner.nullspace import guard_conv_weights
+    return guard_conv_weights(model, max_moves)

@@ -71,6 +71,7 @@ class NullSpaceTaskMixin:
         for name, param in ori.named_parameters():
             if "teacher" in name:
                 param.requires_grad_(False)
+        NS.guard_conv_weights(ori)           # the deep copy allocated new weights (stock MIOpen over-read, see the guard)
         return ori.teacher_model
 
     def set_pseudo_label_thresholds(self, model):
@@ -128,6 +129,7 @@ class NullSpaceTaskMixin:
         ori = NS.unwrap(model)
         ckpt = torch.load(path, map_location=next(ori.parameters()).device, weights_only=True)
         ori.load_state_dict(ckpt["state_dict"] if "state_dict" in ckpt else ckpt, strict=False)
+        NS.guard_conv_weights(ori)
         return path
 
     def load_previous_checkpoint(self, model) -> Optional[str]:
@@ -175,6 +177,7 @@ if HAVE_MMENGINE:  # pragma: no cover - exercised only where mmengine is install
 
         def train(self):
             model = NS.unwrap(self.model)
+            NS.guard_conv_weights(model)         # stock MIOpen 1x1 backward-data over-read (see the guard); again after loads / teacher copy
             self.set_pseudo_label_thresholds(model)                                                   # runner:439-441
             self._train_loop = self.build_train_loop(self._train_loop)
             self.optim_wrapper = self.build_optim_wrapper(self.optim_wrapper)
@@ -187,6 +190,7 @@ if HAVE_MMENGINE:  # pragma: no cover - exercised only where mmengine is install
             self.call_hook("before_run")
             self._init_model_weights()
             self.load_or_resume()
+            NS.guard_conv_weights(model)
             if self.task_id != 1 and not self.is_trained:
                 if "joint" not in self.work_dir:
                     self.attach_teacher(self.model)
@@ -243,6 +247,7 @@ else:
             ``step_fn`` may call ``runner.save_checkpoint(model, 'best_....pth')``; if no file of this task carries
             ``ckpt_keywords`` when the loop ends, the final weights are saved under that keyword."""
             ori = NS.unwrap(self.model)
+            NS.guard_conv_weights(ori)           # stock MIOpen 1x1 backward-data over-read (see the guard); again after loads / teacher copy
             self.set_pseudo_label_thresholds(self.model)                                              # runner:439-441
             if self.task_id != 1:
                 self.load_previous_checkpoint(self.model)                                             # runner:295-299

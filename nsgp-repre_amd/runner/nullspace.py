@@ -258,6 +258,36 @@ def cal_rois(model: nn.Module, batches: Iterable, save_path: Optional[str] = Non
     return gathered
 
 
+def guard_conv_weights(model: nn.Module, max_moves: int = 64) -> int:
+    """Guard against a stock MIOpen defect (profiles/README.md, incident analysis; tools/miopen_overread_repro.py): MIOpen's
+    backward-data kernel of a 1x1 convolution reads past the end of its weight tensor -- a GPU memory access fault when the caching
+    allocator has placed that weight as the LAST block of a segment and nothing is mapped behind it.  Every convolution weight of
+    ``model`` (teacher copy included) that ends exactly where its allocator segment ends is moved to a fresh allocation -- whether
+    or not another segment happens to start there today: ``empty_cache()`` (the reference's ``train`` calls it) can unmap that
+    neighbour later.  The old block stays referenced by the model (``_segment_end_pads``), so no other weight can land in the slot.
+    Both runner faces call this after the model is on the device, after a checkpoint load and after ``attach_teacher`` (the deep
+    copy allocates new weights).  Returns how many weights were moved; a no-op on the CPU; costs one allocator snapshot per pass."""
+    model = unwrap(model)
+    params = [m.weight for m in model.modules() if isinstance(m, nn.Conv2d) and m.weight.is_cuda]
+    if not params:
+        return 0
+    pads = getattr(model, "_segment_end_pads", [])
+    moved = 0
+    for _ in range(max_moves):
+        ends = {s["address"] + s["total_size"] for s in torch.cuda.memory_snapshot()}
+        hit = [p for p in params if (p.data_ptr() + p.numel() * p.element_size()) in ends]
+        if not hit:
+            break
+        for p in hit:
+            pads.append(p.data)                 # keeps the segment-final block occupied
+            p.data = p.data.clone()
+            moved += 1
+    model._segment_end_pads = pads
+    if moved:
+        logger.info("guard_conv_weights: moved %d convolution weight(s) off the end of their allocator segment", moved)
+    return moved
+
+
 def find_checkpoint(directory: str, ckpt_keywords: str) -> str:
     """First directory entry whose name contains ``ckpt_keywords`` (runner:295-299, 710-713)."""
     for f in os.listdir(directory):

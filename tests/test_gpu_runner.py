@@ -206,14 +206,14 @@ def test_two_task_run_keeps_old_features_fixed(N, dev):
                 seen["best"] = {k: v.detach().clone() for k, v in m.state_dict().items()}
             seen["n"] += 1
             return m(b)
-        # MIOpen is switched off for this toy net's training passes -- with proof this time (profiles/README.md, incident analysis;
-        # tools/miopen_overread_repro.py reproduces it with PyTorch + MIOpen alone): MIOpen's backward-data kernel for the 1x1 `neck`
-        # convolution reads past the end of its 512-byte weight tensor.  Harmless while mapped memory follows; when the caching
-        # allocator happens to place neck.weight as the last block of a full 2 MiB segment (it does when test_gpu_detector.py runs
-        # right before this file) the read hits unmapped address space: "Memory access fault by GPU", HSA aborts the process -- the
-        # round-1 "Fatal Python error: Aborted".  No kernel of this repo is involved (no plan exists yet when it happens).
-        with torch.backends.cudnn.flags(enabled=False):
-            cov, _ = r1.train(step1, data1, importance_loss=lambda m, b: m(b))
+        # Round 1's "Fatal Python error: Aborted" lived here: MIOpen's backward-data kernel for the 1x1 `neck` convolution reads past the
+        # end of its 512-byte weight tensor (profiles/README.md, incident analysis; tools/miopen_overread_repro.py reproduces it with
+        # PyTorch + MIOpen alone) -- a GPU memory access fault whenever the caching allocator places neck.weight as the last block of a
+        # segment.  Round 2 ran these passes with MIOpen off; now BOTH runner faces call `guard_conv_weights` (after the model is on the
+        # device, after checkpoint loads, after the teacher copy), so the passes run on MIOpen like a real run does.
+        cov, _ = r1.train(step1, data1, importance_loss=lambda m, b: m(b))
+        assert not any((p.data_ptr() + p.numel() * 4) in {s_["address"] + s_["total_size"] for s_ in torch.cuda.memory_snapshot()}
+                       for p in [m.weight for m in net.modules() if isinstance(m, nn.Conv2d)])
         assert os.path.exists(os.path.join(w1, "covariance.pth")) and len(opt.transforms) == 0
         # runner:710-716: the end-of-task passes run on the RELOADED ckpt_keywords checkpoint, not on the last iteration's weights:
         # the model is back at the saved state, and covariance.pth is the covariance of THAT model (conv2's input depends on conv1 + bn1)
@@ -227,8 +227,7 @@ def test_two_task_run_keeps_old_features_fixed(N, dev):
         before = {n: p.detach().clone() for n, p in net.named_parameters()}
         opt2 = N.SGDNSCL(net.parameters(), lr=0.05, momentum=0.9, svd=True)
         r2 = N.runner.BRNullSpaceRunner(net, opt2, w2, task_id=2, previous_dir=w1, ignore_keys=["rpn", "roi_head"])
-        with torch.backends.cudnn.flags(enabled=False):
-            r2.train(lambda m, b: m(b), data2)
+        r2.train(lambda m, b: m(b), data2)
         assert sorted(opt2.transforms.keys()) == ["backbone.conv1.weight", "backbone.conv2.weight", "fc.weight", "neck.weight"]
         assert "rpn_head.weight" not in opt2.transforms
         name = "backbone.conv1.weight"

