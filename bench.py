@@ -223,6 +223,84 @@ def once_per_task_units(N, dev):
     return out
 
 
+REPRE_CONFIGS = {"v15": dict(K=150, split=[0, 15, 20]), "v10": dict(K=100, split=[0, 10, 20]), "c40": dict(K=400, split=[0, 40, 80])}
+
+
+def repre_step(N, dev, K, split, reps=30):
+    """SURVEY 8(d) metric (ii): the per-step RePRE replay pass alone -- the K-row prototype bank through Shared2FCBBoxHeadTask
+    (12544 -> 1024 -> 1024 -> per-task class heads) and CE(softmax(.)), forward + backward into the head's weight gradients
+    (standard_roi_replay_head.py:468-501, convfc_bbox_head_task.py:235-276) -- HIP events around back-to-back passes on the current
+    stream, median of `reps`.  Three implementations of the same arithmetic: the fused HIP path (default; fp32 MFMA), the
+    module-by-module torch path in fp32 (what round 2 shipped) and that path under bf16 autocast (what the reference's AMP run does).
+    `roofline`: ALGORITHMIC work of one pass = forward + weight gradients only (the bank is a constant: no dX) -- bytes W1 read +
+    dW1 written + the bank read twice + W2 / dW2, FLOPs 2 * 2 K (12544 * 1024 + 1024^2 + C * 1024) -- against both bounds."""
+    torch.manual_seed(7)
+    head = N.roi_heads.Shared2FCBBoxHeadTask(in_channels=256, fc_out_channels=1024, roi_feat_size=7, num_classes=split[-1],
+                                             task_split=list(split), task_id=2).to(dev)
+
+    class Replay(N.roi_heads.PrototypeReplay):
+        pass
+    rp = Replay()
+    rp.bbox_head, rp.task_split, rp.task_id, rp.replay = head, list(split), 2, True
+    rp.bbox_featss = torch.relu(torch.randn(K, 12544, device=dev))
+    rp.tmp_label = torch.randint(0, split[1], (K,), device=dev)
+    C_ = split[2] + 1
+    fin, hid = 12544, 1024
+
+    def one(fused, amp, backward=True):
+        rp.fused_replay = fused
+        head.zero_grad(set_to_none=True)
+        if amp:
+            with torch.autocast("cuda", dtype=torch.bfloat16):
+                loss = rp.replay_loss(rp.bbox_featss)["replay_loss"]["replay_loss_cls"]
+        else:
+            loss = rp.add_replay_loss({})["replay_loss_cls"]
+        if backward:
+            loss.backward()
+        return loss
+
+    def timed(fused, amp, backward=True):
+        for _ in range(3):
+            one(fused, amp, backward)
+        torch.cuda.synchronize()
+        ts = []
+        for _ in range(reps):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            one(fused, amp, backward)
+            e1.record()
+            torch.cuda.synchronize()
+            ts.append(e0.elapsed_time(e1))
+        return sorted(ts)[len(ts) // 2]
+    fused_ms, fused_fwd_ms = timed(True, False), timed(True, False, backward=False)
+    module_ms, bf16_ms = timed(False, False), timed(False, True)
+    # back-to-back (no synchronisation between passes): what the launches cost when the host runs ahead
+    for _ in range(3):
+        one(True, False)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        one(True, False)
+    e1.record()
+    torch.cuda.synchronize()
+    stream_ms = e0.elapsed_time(e1) / reps
+    flops = 2.0 * 2.0 * K * (fin * hid + hid * hid + C_ * hid)
+    nbytes = 4.0 * (2 * hid * fin + 2 * K * fin + 2 * hid * hid + 2 * C_ * hid)
+    rp.fused_replay = True
+    return {"K": K, "task_split": list(split), "kept_class_columns": C_, "repre_step_ms": fused_ms, "forward_only_ms": fused_fwd_ms,
+            "back_to_back_ms": stream_ms, "module_path_fp32_ms": module_ms, "module_path_bf16_autocast_ms": bf16_ms,
+            "launches": "forward: skinny split-K GEMM + slab reduce (x2), class scores, CE = 6; backward: CE, dZ2, skinny GEMM, dZ1, grouped weight-gradient GEMM (x2) = 6 "
+                        "(csrc/replay_head.hip); + torch's cat / split of the per-task class heads",
+            "roofline": {"algorithmic_flops": flops, "algorithmic_bytes": nbytes,
+                         "mfma": {"bound": "mfma", "achieved": flops / (stream_ms * 1e-3) / 1e12, "peak": PEAK_FP32_MATRIX_TFLOPS, "unit": "TFLOP/s",
+                                  "frac": flops / (stream_ms * 1e-3) / 1e12 / PEAK_FP32_MATRIX_TFLOPS},
+                         "hbm": {"bound": "hbm", "achieved": nbytes / (stream_ms * 1e-3) / 1e9, "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                                 "frac": nbytes / (stream_ms * 1e-3) / 1e9 / PEAK_HBM_GBS},
+                         "note": "over the whole pass (12 launches), back-to-back; fp32 MFMA bound 7.7 GFLOP / 157.3 TF = 49 us at K = 150, HBM bound 118 MB / 8 TB/s = 15 us; "
+                                 "per-kernel durations: profiles/r03"}}
+
+
 def make_basis(D, dev, seed):
     """(V, first) for one layer width, the way a run produces them: C = X^T X with X = [4D x D] ~ N(0,1) *
     diag(logspace(0,-3,D)) seeded, its eigenbasis by eigh on the GPU (descending), and the adaptive elbow index = the number
@@ -288,11 +366,41 @@ def cpu_baseline(table, seconds_budget=15.0):
             break
     timed = times[1:]   # first call = warm-up (thread pool, page faults)
     step_ms = sorted(timed)[len(timed) // 2] * 1e3
+    # ---- the RePRE replay pass on the same cores: the oracle's task head + double-softmax CE, forward + backward (torch-CPU autograd),
+    # K = 150 prototypes through 12544 -> 1024 -> 1024 -> (15 | 5 | 1) -- standard_roi_replay_head.py:468-501
+    K, split = 150, [0, 15, 20]
+
+    def lin(o, i):
+        return (torch.randn(o, i, generator=g) * (1.0 / i ** 0.5)).requires_grad_(True), torch.zeros(o, requires_grad=True)
+    shared = [lin(1024, 12544), lin(1024, 1024)]
+    fc_cls = [lin(15, 1024), lin(5, 1024), lin(1, 1024)]
+    fc_reg = [lin(60, 1024), lin(20, 1024)]
+    bank = torch.relu(torch.randn(K, 12544, generator=g))
+    labels = torch.randint(0, 15, (K,), generator=g)
+    leaves = [t for pair in shared + fc_cls for t in pair]
+    rtimes = []
+    t_all = time.perf_counter()
+    while True:
+        for t in leaves:
+            t.grad = None
+        t0 = time.perf_counter()
+        cls, _ = O.task_head_forward(bank, shared, fc_cls, fc_reg, 2, len(split))
+        O.replay_loss_from_scores(cls, labels, split[2]).backward()
+        rtimes.append(time.perf_counter() - t0)
+        if (time.perf_counter() - t_all > seconds_budget / 2 and len(rtimes) >= 4) or len(rtimes) >= 200:
+            break
+    repre_ms = sorted(rtimes[1:])[len(rtimes[1:]) // 2] * 1e3
+    return dict(repre_step_ms=repre_ms, nsgp_plus_repre_step_ms=step_ms + repre_ms,
+                repre_sample=f"oracle task_head_forward + replay_loss_from_scores, forward + backward, K = 150: 1 warm-up + median of {len(rtimes) - 1} passes",
+                **_cpu_nsgp_fields(step_ms, timed, seconds_budget))
+
+
+def _cpu_nsgp_fields(step_ms, timed, seconds_budget):
     return dict(value=1e3 / step_ms, unit="NSGP projected steps/s (= images/s of the hot path alone at 1 image per step; the detector is not run on the CPU side)",
                 cores=torch.get_num_threads(), kind="port", step_ms=step_ms,
                 sample=f"oracle SGDNSCL.step over the full R-50-FPN table (162 tensors, 50 projected, 118.3 GFLOP): "
-                       f"1 warm-up + median of {len(timed)} steps in ~{seconds_budget:.0f} s; the replay loss is not "
-                       "included on the CPU side (that favours the CPU number)")
+                       f"1 warm-up + median of {len(timed)} steps in ~{seconds_budget:.0f} s; the RePRE replay pass is timed beside it "
+                       "(repre_step_ms)")
 
 
 PEAK_16BIT_MATRIX_TFLOPS = 2500.0   # dense fp16 / bf16 MFMA peak (MI355X_MICROARCH.md)
@@ -347,8 +455,12 @@ def roofline_block(split, flops, abytes_kernel, gemm_ms, update_ms, n_prof, nume
                     "lowrank_reduce_ms": reduce_ms,
                     "lowrank_apply": hbm("nsgp_lr_apply_kernel<SGD> (p += c (u - T U^T), exact fp32 MFMA, K = r)", apply_ms, 12 * proj_numel,
                                          "reads the update, reads and writes p = 12 B per projected element"),
-                    "step_algorithmic_bytes": 20 * proj_numel + 24 * plain_numel + 12 * proj_numel,
-                    "step_hbm_gbs": (20 * proj_numel + 24 * plain_numel + 12 * proj_numel) / ((plain_ms + fused_ms + reduce_ms + apply_ms) * 1e-3) / 1e9,
+                    "step_bytes_moved_by_the_launches": 20 * proj_numel + 24 * plain_numel + 12 * proj_numel,
+                    "step_bytes_moved_note": "what the four launches move: the apply launch re-reads the update and p of the projected layers (12 B / element) because T = u U "
+                                             "must be complete first -- 32 B per projected element where SURVEY 8(d)'s algorithmic count is 24",
+                    "step_launch_gbs": (20 * proj_numel + 24 * plain_numel + 12 * proj_numel) / ((plain_ms + fused_ms + reduce_ms + apply_ms) * 1e-3) / 1e9,
+                    "step_8d_bytes": 24 * numel,
+                    "step_frac_vs_8d_bytes": 24 * numel / ((plain_ms + fused_ms + reduce_ms + apply_ms) * 1e-3) / 1e9 / PEAK_HBM_GBS,
                     "lowrank_apply_traffic": tr.get("nsgp_lr_apply_kernel_hbm_bytes_per_launch"),
                     "mfma_busy_fraction_pmc": tr.get("nsgp_update_lr_kernel_mfma_busy_fraction"),
                     "lowrank_flops": lowrank[1], "dense_form_flops": flops,
@@ -358,10 +470,10 @@ def roofline_block(split, flops, abytes_kernel, gemm_ms, update_ms, n_prof, nume
                                              "hot_path.mfma_paths / hot_path.roofline_dense_f16x2"})
         return out
     alg_tf = flops / (gemm_ms * 1e-3) / 1e12
-    mult = {"bf16x3": 6, "f16x2": 3}.get(split, 1)
+    mult = {"f16x2": 3}.get(split, 1)
     peak = PEAK_16BIT_MATRIX_TFLOPS if split else PEAK_FP32_MATRIX_TFLOPS
     kernel = {"f16x2": "nsgp_project_v2_kernel<SGD> (256x128 tiles, LDS-DMA, two-term fp16 split with per-row / per-column scales)",
-              "bf16x3": "nsgp_project_kernel<SGD,fast,bf16x3> (three-term bf16 split)"}.get(split, "nsgp_project_kernel<SGD,fast> (fp32 MFMA)")
+              }.get(split, "nsgp_project_kernel<SGD,fast> (fp32 MFMA)")
     out = {"bound": "mfma", "kernel": kernel, "achieved": alg_tf, "peak": peak, "unit": "TFLOP/s", "frac": alg_tf / peak,
            "executed_flops_per_algorithmic_flop": mult, "executed_mfma_utilisation": mult * alg_tf / peak,
            "vs_fp32_matrix_peak": alg_tf / PEAK_FP32_MATRIX_TFLOPS,
@@ -379,24 +491,44 @@ def roofline_block(split, flops, abytes_kernel, gemm_ms, update_ms, n_prof, nume
     return out
 
 
-def end_to_end_training(N, dev, world, local_rank, basis_cache, steps, warmup, amp, batch_size=1):
+def end_to_end_training(N, dev, world, local_rank, basis_cache, steps, warmup, amp, batch_size=1, split=(0, 15, 20), K=150):
     """SURVEY 8(d) "end-to-end img/s": the whole task-2 training step of cl_faster_rcnn_nsgp_repre_15_5_2.py on synthetic
     800x1344 batches -- teacher predict + pseudo-label filter, student forward (RPN + RoI losses + replay loss on the
     K=150 bank), backward (DDP bucketed RCCL all-reduce overlapped with it when world > 1) and the projected SGDNSCL
     step.  The detector is nsgp_repre_amd.detection (stock recipe in plain PyTorch-ROCm; mmdet is not in the image)."""
     import copy
+    import tempfile
     import torch.distributed as dist
     from nsgp_repre_amd.detection import build_faster_rcnn, relocate_segment_final_weights, synthetic_batch
     torch.manual_seed(4321)
-    model = build_faster_rcnn(depth=50, num_classes=20, task_id=2, task_split=[0, 15, 20]).to(dev)
+    split = list(split)
+    model = build_faster_rcnn(depth=50, num_classes=split[-1], task_id=2, task_split=split).to(dev)
     relocate_segment_final_weights(model)      # guard against a stock MIOpen over-read (profiles/README.md, incident analysis)
     head = model.roi_head
-    head.replay, K = True, 150
-    head.bbox_featss = torch.relu(torch.randn(K, 12544, device=dev))
-    head.tmp_label = torch.randint(0, 15, (K,), device=dev)
     mix = N.runner.br_nullspace_runner.NullSpaceTaskMixin()
     mix.task_id = 2
+    # EWC on the BatchNorm parameters (runner:558-565, 946-1073): the importance of "task 1" from a seeded pass over two synthetic
+    # old-class batches (calculate_save_importance, before the teacher exists), loaded back and hooked onto model.loss like the
+    # reference's task-2 start does -- so the timed step carries `ewc_loss` (and its backward)
+    tmp = tempfile.mkdtemp(prefix="nsgp_bench_")
+    mix._task_work_dir, mix.previous_dir, mix.reg_params, mix.ewc_reg_terms = tmp, tmp, {}, {}
+    old_batches = [synthetic_batch(1, (split[0], split[1]), dev, seed=900 + 10 * local_rank + i) for i in range(2)]
+
+    def importance_loss(m, b):
+        with torch.autocast("cuda", dtype=torch.bfloat16, enabled=amp):
+            losses = m(b[0], copy.deepcopy(b[1]), mode="loss")
+        return sum(v for k, v in losses.items() if "loss" in k)
+    model.train()
+    mix.calculate_save_importance(model, old_batches, importance_loss)
+    model.train()
+    head.replay = True
+    head.bbox_featss = torch.relu(torch.randn(K, 12544, device=dev))
+    head.tmp_label = torch.randint(0, split[1], (K,), device=dev)
     mix.attach_teacher(model)                                  # runner:527-547
+    mix.load_importance(model)                                 # runner:558
+    mix.wrap_loss_with_ewc(model)                              # runner:559-565
+    import shutil
+    shutil.rmtree(tmp, ignore_errors=True)
     opt = N.SGDNSCL(model.parameters(), lr=0.02, momentum=0.9, weight_decay=1e-4, svd=True)
     N.runner.nullspace.wire_param_names(opt, model)             # runner:473-484
     ignore = N.runner.nullspace.full_ignore_keys(["rpn", "roi_head"])
@@ -409,7 +541,7 @@ def end_to_end_training(N, dev, world, local_rank, basis_cache, steps, warmup, a
             opt.set_basis(n, basis_cache[D][0], basis_cache[D][1])
             n_proj += 1
     model.train()
-    batches = [synthetic_batch(batch_size, (15, 20), dev, seed=100 * local_rank + i) for i in range(4)]
+    batches = [synthetic_batch(batch_size, (split[1], split[2]), dev, seed=100 * local_rank + i) for i in range(4)]
     net = model
     if world > 1:
         # find_unused_parameters=True is the reference's own setting (_base_/brnsrunetime.py:27); the frozen heads of future tasks
@@ -473,7 +605,8 @@ def end_to_end_training(N, dev, world, local_rank, basis_cache, steps, warmup, a
                              n_prof=n_prof, numel=all_numel, ntiles=ntiles, nproj=nproj, detail=detail, lowrank=lowrank,
                              proj_numel=proj_numel, proj_bytes=proj_bytes),
            "nsgp_launch_ms": dict(zip(("update", "update_lr_fused_t", "dense_gemm", "lowrank_reduce", "lowrank_apply"), detail)),
-           "layers_on_low_rank_form": lowrank[0],
+           "layers_on_low_rank_form": lowrank[0], "prototype_bank_rows": K, "task_split": split,
+           "host_cores_per_rank": host_cores(),
            "trainable_tensors": sum(len(g["params"]) for g in opt.param_groups),
            "losses_finite": finite, "loss_keys": sorted(losses.keys()),
            "detector_dtype": "bf16 autocast (replay-bank pass, losses, NSGP step fp32)" if amp else "f32",
@@ -530,7 +663,7 @@ def hot_path_only(N, dev, args, cache):
 
     def one_step():
         flat_grads.copy_(synth_flat)           # the detector's backward() writes the grads (synthetic)
-        loss = replay.replay_loss(replay.bbox_featss)["replay_loss"]["replay_loss_cls"]   # RePRE replay loss: forward
+        loss = replay.add_replay_loss({})["replay_loss_cls"]   # RePRE replay pass, forward: the fused HIP path (csrc/replay_head.hip)
         loss.backward()                        # + backward: accumulates into the head's grad views
         h0 = time.perf_counter()
         opt.step()                             # NSGP projected step: 4 HIP launches on the default path
@@ -582,7 +715,7 @@ def hot_path_only(N, dev, args, cache):
         opt.mutate_grad = True
     # ---- the dense GEMM on every MFMA path, with the SAME projectors (what externally assigned projectors run on)
     opt.low_rank = False
-    for path in ("f16x2", "bf16x3", False):
+    for path in ("f16x2", False):
         opt.split_mfma = path
         ms, u_ms, g_ms = timed(args.steps)
         tf = flops / (g_ms * 1e-3) / 1e12
@@ -635,7 +768,10 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="headline only: skip hot_path / once_per_task / cpu_baseline")
     ap.add_argument("--f32-detector", action="store_true", help="run the detector in fp32 instead of bf16 autocast (the NSGP step is fp32 either way)")
-    ap.add_argument("--batch-per-gpu", type=int, default=1)
+    ap.add_argument("--batch-per-gpu", type=int, default=None)
+    ap.add_argument("--config", choices=("v15", "v10"), default="v15",
+                    help="v15 (default) = BASELINE configs[1]: VOC 15+5 task 2, 1 image per GPU, K = 150; v10 = configs[2]'s per-GPU step: VOC 10+10 "
+                         "task 2 (split [0,10,20]), 16 images per GPU (voc_10_10_task2_2007.py:40), K = 100")
     ap.add_argument("--hot-path-only", action="store_true", help="profiling aid (tools/profile.sh): only the `hot_path` block -- the projected "
                     "step on every MFMA path + replay loss on synthetic gradients -- no detector, no once-per-task units")
     args = ap.parse_args()
@@ -659,12 +795,17 @@ def main():
     import nsgp_repre_amd as N
 
     cache = {}
+    wl = {"v15": dict(split=(0, 15, 20), K=150, batch=1, name="R-50-FPN VOC 15+5 task 2 (configs[1])"),
+          "v10": dict(split=(0, 10, 20), K=100, batch=16, name="R-50-FPN VOC 10+10 task 2 (configs[2], per-GPU step)")}[args.config]
+    if args.batch_per_gpu is None:
+        args.batch_per_gpu = wl["batch"]
     if args.hot_path_only:
         hp, _ = hot_path_only(N, dev, args, cache)
-        print(json.dumps({"hot_path": hp}))
+        print(json.dumps({"hot_path": hp, "repre": {"v15": repre_step(N, dev, **REPRE_CONFIGS["v15"])}}))
         return
     # ---- the headline: K full training iterations, DDP gradient all-reduce inside for N > 1
-    e2e = end_to_end_training(N, dev, world, local_rank, cache, args.steps, args.warmup, not args.f32_detector, batch_size=args.batch_per_gpu)
+    e2e = end_to_end_training(N, dev, world, local_rank, cache, args.steps, args.warmup, not args.f32_detector, batch_size=args.batch_per_gpu,
+                              split=wl["split"], K=wl["K"])
     if rank == 0:
         rf = e2e.pop("_roofline")
         out = {
@@ -672,11 +813,17 @@ def main():
             "value": e2e["img_s"], "unit": "img/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": e2e["ms_per_step"],
             "nsgp_step_ms": rf["update_ms"] + rf["gemm_ms"],
+            "repre_step_ms": None, "covariance_forward_ms": None,      # filled from hot_path.repre / once_per_task below (N = 1)
+            # SURVEY 8(d)'s bytes for the whole step -- g r(+w), buf r+w, p r+w = 24 B per element of every tensor the step touches --
+            # over the step's launches, against 8 TB/s (the per-launch fractions are in `roofline`)
+            "step_frac_vs_8d_bytes": 24.0 * rf["numel"] / ((rf["update_ms"] + rf["gemm_ms"]) * 1e-3) / 1e9 / PEAK_HBM_GBS,
+            "layers_on_low_rank": f"{e2e['layers_on_low_rank_form']}/{e2e['projected_layers']}",
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32 (NSGP step: parameters, gradients, state and every product -- the low-rank form runs on the exact fp32 MFMA)"
                      + ("" if args.f32_detector else "; detector forward/backward under bf16 autocast"),
             "data": "synthetic",
-            "config": {"workload": "R-50-FPN VOC 15+5 task 2 (configs[1]), 1 synthetic 3x800x1344 image per GPU per step, 50 projected layers, K=150 prototype bank",
+            "config": {"workload": f"{wl['name']}, {args.batch_per_gpu} synthetic 3x800x1344 image(s) per GPU per step, 50 projected layers, "
+                                   f"K={wl['K']} prototype bank, EWC on the BatchNorm parameters",
                        "global_batch": world * args.batch_per_gpu, "parallelism": f"ddp{world}" if world > 1 else "single"},
             "roofline": roofline_block(**rf),
             "training_step": e2e,
@@ -697,14 +844,26 @@ def main():
             guarded("hot_path", _hot)
             if not args.f32_detector:    # the same training step with an fp32 detector, beside the bf16 number
                 def _f32():
-                    r = end_to_end_training(N, dev, world, local_rank, cache, max(4, args.steps // 2), 3, False, batch_size=args.batch_per_gpu)
+                    r = end_to_end_training(N, dev, world, local_rank, cache, max(4, args.steps // 2), 3, False, batch_size=args.batch_per_gpu,
+                                            split=wl["split"], K=wl["K"])
                     return {k: r[k] for k in ("img_s", "ms_per_step", "teacher_student_fwd_bwd_ms", "optimizer_step_ms", "losses_finite")}
                 guarded("training_step_f32_detector", _f32)
+            guarded("repre", lambda: {name: repre_step(N, dev, c["K"], c["split"]) for name, c in REPRE_CONFIGS.items()})
+            if isinstance(out.get("repre"), dict) and args.config in out["repre"]:
+                out["repre_step_ms"] = out["repre"][args.config].get("repre_step_ms")
             guarded("once_per_task", lambda: once_per_task_units(N, dev))
+            try:
+                out["covariance_forward_ms"] = out["once_per_task"]["covariance_forward_r50"]["ms"]
+            except Exception:
+                pass
             if not args.no_cpu_baseline:
                 def _cpu():
                     cb = cpu_baseline(table_box.get("table") or r50_fpn_voc_parameter_table())
                     cb["gpu_nsgp_step_speedup"] = cb["step_ms"] / out["nsgp_step_ms"]
+                    if out.get("repre_step_ms"):      # the north star's ratio: NSGP projection + RePRE step, GPU vs the CPU path on this host
+                        cb["gpu_repre_step_speedup"] = cb["repre_step_ms"] / out["repre_step_ms"]
+                        cb["gpu_nsgp_plus_repre_step_ms"] = out["nsgp_step_ms"] + out["repre_step_ms"]
+                        cb["gpu_nsgp_plus_repre_speedup"] = cb["nsgp_plus_repre_step_ms"] / cb["gpu_nsgp_plus_repre_step_ms"]
                     return cb
                 guarded("cpu_baseline", _cpu)
         print(json.dumps(out))

@@ -89,12 +89,12 @@ typedef struct {
                            proj == basis_scale * (I - U U^T) as built by nsgp_build_projector_head from the same U;
                            otherwise leave both NULL and the dense `proj` is used */
     float basis_scale;  /* 1/||I - U U^T||_F for Frobenius-normalised projectors (SGD_NSCL.py:282-283), else 1 */
-    int32_t split_kind; /* 0: no split copy; 1: proj_split holds the three-term bf16 split (nsgp_split_projector);
-                           2: the pre-tiled, column-scaled two-term fp16 split (nsgp_split_projector_f16) */
+    int32_t split_kind; /* 0: no split copy; 2: proj_split holds the pre-tiled, column-scaled two-term fp16 split
+                           (nsgp_split_projector_f16).  (1 was a three-term bf16 split: slower than kind 2 on every table and never a
+                           default; removed in ABI 8.) */
     const void* proj_split; /* optional split copy of proj^T.  When every 128-aligned projected tensor of a plan carries one
                            of the same kind, the dense projection runs on the low-precision matrix cores with fp32 accumulation
-                           and fp32-level error PER OUTPUT ROW: kind 1 = six bf16 MFMAs per product (a0b0+a0b1+a1b0+a0b2+a1b1+a2b0),
-                           kind 2 = three fp16 MFMAs per product (a0b0+a0b1+a1b0) with one power-of-two scale per ROW of the
+                           and fp32-level error PER OUTPUT ROW: three fp16 MFMAs per product (a0b0+a0b1+a1b0) with one power-of-two scale per ROW of the
                            update (found by the elementwise launch of the same step, which also writes the update's split
                            copy into the plan workspace) and one per COLUMN of the projector (stored behind the split copy).
                            NULL = fp32 MFMA */
@@ -165,11 +165,6 @@ int nsgp_plan_profile_end(nsgp_plan_t* plan, int* n_steps, float* update_ms_avg,
  * launch(es), [3] the slab reduce of the low-rank T, [4] the low-rank apply launch.  (_end's update_ms = [0] + [1], gemm_ms = the rest.) */
 int nsgp_plan_profile_detail(const nsgp_plan_t* plan, float* ms5);
 
-/* Three-term bf16 split of the TRANSPOSE of a projector (proj = sum of the three terms to 24 mantissa bits), in the layout
- * the split-MFMA projection kernel streams: [n][k/8][term][8] bf16, 6 bytes per element.  Once per projector per task.
- * proj: [D x D] fp32 row-major; out: >= nsgp_split_projector_bytes(D) bytes, 16-byte aligned; D % 8 == 0. */
-size_t nsgp_split_projector_bytes(int D);
-int nsgp_split_projector(const float* proj, int D, void* out, void* stream);
 /* Two-term fp16 split of diag(c) * proj^T with c[n] the power of two that brings the largest |entry| of projector column n
  * into [2^13, 2^14) (fp16 overflows at 65504).  `out` (16-byte aligned, nsgp_split_projector_f16_bytes(D) bytes, D % 64 == 0):
  *   [n / 64][k / 8][term][n % 64][8 fp16]   D*D*4 bytes -- 1 KiB planes, the unit the projection kernel moves by LDS-DMA

@@ -65,8 +65,6 @@ SIGNATURES = {
                                   + [C.c_size_t, C.c_void_p]),
     "repre_replay_head_backward": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int] + [C.c_void_p] * 12
                                    + [C.c_size_t, C.c_void_p]),
-    "nsgp_split_projector_bytes": (C.c_size_t, [C.c_int]),
-    "nsgp_split_projector": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
     "nsgp_plan_uses_split_mfma": (C.c_int, [C.c_void_p]),
     "nsgp_plan_tile_counts": (C.c_int, [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "nsgp_cov_set_split_mfma": (C.c_int, [C.c_int]),

@@ -2,7 +2,7 @@
 //   a = a0 + a1 with a0 = fp16(a), a1 = fp16(a - a0): 2 x 11 = 22 mantissa bits per operand, and
 //       a*b ~= a1 b0 + a0 b1 + a0 b0            (the dropped a1 b1 is <= 2^-22 |a b|)
 //   is THREE v_mfma_f32_32x32x16_f16 per fp32-equivalent product, accumulated in fp32 -- half the MFMAs and two thirds of the
-//   operand bytes of the three-term bf16 split (gemm_bf16x3.hpp), which the L2 -> CU path bounds.  Measured against fp64 on 4096^3
+//   operand bytes of the three-term bf16 split this repo shipped until round 2, which the L2 -> CU path bounds.  Measured against fp64 on 4096^3
 //   (a quarter of the entries 4-5 decades smaller than the rest): max error 1.4e-6 of max|C|, the fp32 MFMA's own level.
 // fp16 has a 5-bit exponent, so each operand matrix carries ONE power-of-two scale that puts its largest magnitude in
 // [2^13, 2^14) (fp16 max 65504): elements down to 2^-27 of the largest stay normal in a0, anything smaller loses only bits
@@ -11,7 +11,7 @@
 //   A  [M x K] fp32 row-major, scaled by `a_scale` and split while it is written to LDS;
 //   Bt the two fp16 terms of the TRANSPOSED, pre-scaled right operand, global layout [n][k/8][term][8] (4 bytes per
 //      element), written once per projector by nsgp_split_transpose_f16x2_kernel.
-// Tile / pipeline exactly as gemm_bf16x3.hpp: 128 x 128, 4 waves, k16 steps, [k/8][row][8] LDS images (octet planes
+// Tile / pipeline: 128 x 128, 4 waves, k16 steps, [k/8][row][8] LDS images (octet planes
 // padded by 64 B), two LDS stages + three register sets.
 #pragma once
 #include "gemm_core.hpp"

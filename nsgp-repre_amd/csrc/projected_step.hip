@@ -25,7 +25,6 @@
 
 #include "common.hpp"
 #include "gemm_core.hpp"
-#include "gemm_bf16x3.hpp"
 #include "gemm_f16x2.hpp"
 #include "gemm_f16x2_v2.hpp"
 
@@ -64,7 +63,7 @@ struct LayerDev {
     float* slabs;       // nsplit > 1: [nsplit][rows][rpad] partial T of each K range
     int rank, rpad, nsplit;
     float basis_scale;
-    const void* split;     // split copy of proj^T: kind 1 = three bf16 terms (gemm_bf16x3.hpp), 2 = pre-tiled column-scaled fp16 pair (gemm_f16x2_v2.hpp)
+    const void* split;     // split copy of proj^T: kind 2 = pre-tiled column-scaled fp16 pair (gemm_f16x2_v2.hpp)
     int split_kind;
     int pad;
     const float* cinv;     // kind 2: 1 / (power-of-two scale of each projector column), D floats behind the split copy
@@ -309,7 +308,7 @@ __device__ __forceinline__ void store_tile(float* __restrict__ C, long ldc, int 
         }
 }
 
-template <int OPT, bool FAST, int SPLIT = 0>
+template <int OPT, bool FAST>
 __global__ __launch_bounds__(256, 2) void nsgp_project_kernel(const TileDev* __restrict__ tiles,
                                                               const LayerDev* __restrict__ layers,
                                                               const DynBlock* __restrict__ dyn) {
@@ -332,9 +331,7 @@ __global__ __launch_bounds__(256, 2) void nsgp_project_kernel(const TileDev* __r
     zero_acc(acc);
     // the grad pointer is only known at step time: a misaligned one (e.g. a view into a flat
     // bucket) takes the guarded scalar loader for the A operand only
-    if (SPLIT == 1 && ((uintptr_t)A & 15u) == 0)                 // six bf16 MFMAs per fp32-equivalent product (gemm_bf16x3.hpp)
-        gemm_tile_bf16x3(A, L.cols, static_cast<const __bf16*>(L.split), L.cols, t.m0, t.n0, smem, acc);
-    else if (!FAST || ((uintptr_t)A & 15u) == 0)
+    if (!FAST || ((uintptr_t)A & 15u) == 0)
         gemm_tile<FAST, FAST, false>(A, L.cols, L.proj, L.cols, L.rows, L.cols, L.cols, t.m0, t.n0, smem, acc);
     else
         gemm_tile<false, true, false>(A, L.cols, L.proj, L.cols, L.rows, L.cols, L.cols, t.m0, t.n0, smem, acc);
@@ -705,7 +702,7 @@ __global__ __launch_bounds__(256) void nsgp_lr_apply_kernel(const TileDev* __res
 template <typename K>
 static int enable_big_lds(K kernel) {
     NSGP_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel),
-                                 hipFuncAttributeMaxDynamicSharedMemorySize, X3_SMEM_BYTES > SMEM_BYTES ? X3_SMEM_BYTES : SMEM_BYTES));
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, SMEM_BYTES));
     return NSGP_OK;
 }
 
@@ -726,7 +723,7 @@ struct nsgp_plan {
     int n_chunks = 0;
     int n_tiles_fast = 0, n_tiles_generic = 0;
     int n_tiles_v2 = 0;         // 256 x 128 / 128 x 128 tiles of the fp16-split kernel (split_kind 2); they replace the fast tiles
-    int split_kind = 0;         // dense fast tiles: 0 fp32 MFMA, 1 three-term bf16 split, 2 two-term fp16 split
+    int split_kind = 0;         // dense fast tiles: 0 fp32 MFMA, 2 two-term fp16 split (1 was the three-term bf16 split, removed in ABI 8)
     double gemm_flops = 0, bytes = 0;
     TensorDev* d_tensors = nullptr;
     LayerDev* d_layers = nullptr;
@@ -856,7 +853,7 @@ extern "C" int nsgp_plan_create(nsgp_plan_t** out, const nsgp_tensor_t* tensors,
             ld.push_back(L);
             layer_fast.push_back(tensor_fast(t) && aligned16(t.param) && aligned16(t.state0) ? 1 : 0);
             if (layer_fast.back() && !tensor_lowrank(t)) {
-                const bool ok = t.proj_split && aligned16(t.proj_split) && (t.split_kind == 1 || t.split_kind == 2);
+                const bool ok = t.proj_split && aligned16(t.proj_split) && t.split_kind == 2;
                 if (!ok) all_split = false;
                 else if (split_kind == 0) split_kind = t.split_kind;
                 else if (split_kind != t.split_kind) all_split = false;
@@ -1062,7 +1059,6 @@ extern "C" int nsgp_plan_create(nsgp_plan_t** out, const nsgp_tensor_t* tensors,
     int rc;
     if ((rc = enable_big_lds(nsgp_project_kernel<NSGP_OPT_SGD, true>)) || (rc = enable_big_lds(nsgp_project_kernel<NSGP_OPT_SGD, false>)) ||
         (rc = enable_big_lds(nsgp_project_kernel<NSGP_OPT_ADAM, true>)) || (rc = enable_big_lds(nsgp_project_kernel<NSGP_OPT_ADAM, false>)) ||
-        (rc = enable_big_lds(nsgp_project_kernel<NSGP_OPT_SGD, true, 1>)) || (rc = enable_big_lds(nsgp_project_kernel<NSGP_OPT_ADAM, true, 1>)) ||
         (rc = enable_v2_lds(nsgp_project_v2_kernel<NSGP_OPT_SGD>)) || (rc = enable_v2_lds(nsgp_project_v2_kernel<NSGP_OPT_ADAM>))) {
         nsgp_plan_destroy(P);
         return rc;
@@ -1140,17 +1136,6 @@ extern "C" int nsgp_split_projector_f16(const float* proj, int D, void* out, voi
     return NSGP_OK;
 }
 
-extern "C" size_t nsgp_split_projector_bytes(int D) { return D > 0 ? (size_t)D * D * 6 : 0; }
-
-extern "C" int nsgp_split_projector(const float* proj, int D, void* out, void* stream_) {
-    if (!proj || !out || D <= 0 || D % 8 != 0) return fail(NSGP_ERR_INVALID, "nsgp_split_projector: bad argument (D must be a multiple of 8)");
-    if (!aligned16(out)) return fail(NSGP_ERR_INVALID, "nsgp_split_projector: output must be 16-byte aligned");
-    hipLaunchKernelGGL(nsgp_split_transpose_bf16x3_kernel, dim3((D + 31) / 32, (D + 31) / 32), dim3(256), 0, static_cast<hipStream_t>(stream_),
-                       proj, D, D, static_cast<__bf16*>(out));
-    NSGP_LAUNCH_CHECK();
-    return NSGP_OK;
-}
-
 extern "C" int nsgp_plan_step(nsgp_plan_t* P, float* const* grads, const nsgp_hyper_t* hyper, int n_hyper,
                               void* stream_) {
     if (!P || !grads || !hyper) return fail(NSGP_ERR_INVALID, "nsgp_plan_step: null argument");
@@ -1197,12 +1182,7 @@ extern "C" int nsgp_plan_step(nsgp_plan_t* P, float* const* grads, const nsgp_hy
         NSGP_LAUNCH_CHECK();
     }
     if (P->n_tiles_fast > 0) {
-        if (P->split_kind == 1) {
-            if (P->optimizer == NSGP_OPT_SGD)
-                hipLaunchKernelGGL((nsgp_project_kernel<NSGP_OPT_SGD, true, 1>), dim3(P->n_tiles_fast), dim3(THREADS), X3_SMEM_BYTES, stream, P->d_tiles, P->d_layers, d);
-            else
-                hipLaunchKernelGGL((nsgp_project_kernel<NSGP_OPT_ADAM, true, 1>), dim3(P->n_tiles_fast), dim3(THREADS), X3_SMEM_BYTES, stream, P->d_tiles, P->d_layers, d);
-        } else if (P->optimizer == NSGP_OPT_SGD)
+        if (P->optimizer == NSGP_OPT_SGD)
             hipLaunchKernelGGL((nsgp_project_kernel<NSGP_OPT_SGD, true>), dim3(P->n_tiles_fast), dim3(THREADS), SMEM_BYTES, stream, P->d_tiles, P->d_layers, d);
         else
             hipLaunchKernelGGL((nsgp_project_kernel<NSGP_OPT_ADAM, true>), dim3(P->n_tiles_fast), dim3(THREADS), SMEM_BYTES, stream, P->d_tiles, P->d_layers, d);

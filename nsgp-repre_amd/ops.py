@@ -48,18 +48,6 @@ def project(a: torch.Tensor, proj: torch.Tensor, scale: float = 1.0, out: torch.
     return out if fresh else _touched(out)
 
 
-def split_projector(P: torch.Tensor) -> torch.Tensor:
-    """Three-term bf16 split of ``P^T`` in the layout the split-MFMA projection streams ([n][k/8][term][8], 6 bytes per
-    element of P); ``sum of the terms == P`` to 24 mantissa bits.  One launch per projector per task."""
-    lib = _lib.load_library()
-    D = P.shape[0]
-    if P.shape != (D, D):
-        raise ValueError("projector must be square")
-    out = torch.empty(lib.nsgp_split_projector_bytes(D) // 2, dtype=torch.bfloat16, device=P.device)
-    _lib.check(lib.nsgp_split_projector(_dev(P, "P"), D, C.c_void_p(out.data_ptr()), _stream()), "nsgp_split_projector")
-    return out
-
-
 def split_projector_f16(P: torch.Tensor) -> torch.Tensor:
     """Pre-tiled two-term fp16 split of ``diag(c) P^T`` with one power-of-two scale ``c[n]`` per projector column (largest
     |entry| of the column into [2^13, 2^14); fp16 overflows at 65504), as one uint8 buffer:

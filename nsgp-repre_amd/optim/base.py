@@ -30,9 +30,9 @@ logger = logging.getLogger("nsgp_repre_amd")
 #: largest number of removed directions the low-rank form of the step takes (csrc/projected_step.hip: LR_MAX_RANK)
 LOW_RANK_MAX = 128
 
-#: default of ``optimizer.split_mfma`` (see NSCLOptimizerBase.__init__): False | "bf16x3" | "f16x2" (True = "f16x2")
+#: default of ``optimizer.split_mfma`` (see NSCLOptimizerBase.__init__): False | "f16x2" (True = "f16x2")
 SPLIT_MFMA_DEFAULT = "f16x2"
-_SPLIT_KINDS = {False: 0, None: 0, "f32": 0, "bf16x3": 1, "f16x2": 2, True: 2}
+_SPLIT_KINDS = {False: 0, None: 0, "f32": 0, "f16x2": 2, True: 2}
 
 #: plan handles of optimizers that were garbage-collected without ``close()``.  ``__del__`` may run wherever the
 #: interpreter happens to collect -- on an autograd thread, in the middle of another test's backward -- so it makes NO HIP
@@ -81,11 +81,11 @@ class NSCLOptimizerBase(Optimizer):
         #: orthonormalise the r head vectors (one Newton-Schulz step U <- U (1.5 I - 0.5 U^T U): an fp32 eigh leaves them
         #: orthonormal to ~1e-6, afterwards to ~1e-12) before the head-form projector is built from them
         self.polish_basis = True
-        #: dense projection on the low-precision matrix cores with fp32 accumulation and fp32-level error:
+        #: dense projection on the fp16 matrix cores with fp32 accumulation and fp32-level error per output row:
         #: "f16x2" (default) -- two fp16 terms per operand, three MFMAs per fp32-equivalent product, one power-of-two scale
-        #: per operand matrix (csrc/gemm_f16x2.hpp; 4 extra bytes per projector element); "bf16x3" -- three bf16 terms, six
-        #: MFMAs, no scales (csrc/gemm_bf16x3.hpp; 6 extra bytes).  The split copy of a projector is made once and redone
-        #: if the projector tensor is replaced or modified in place.  False = fp32 MFMA.
+        #: per row of the update and per column of the projector (csrc/gemm_f16x2_v2.hpp; 4 extra bytes per projector element).
+        #: The split copy of a projector is made once and redone if the projector tensor is replaced or modified in place.
+        #: False = fp32 MFMA.  (A three-term bf16 split existed until round 2: slower on every table, removed.)
         self.split_mfma = SPLIT_MFMA_DEFAULT
         #: get_eigens: at most this many equal-width covariances per batched eigh call (1 = one call per layer)
         self.eigh_batch = 16
@@ -329,7 +329,7 @@ class NSCLOptimizerBase(Optimizer):
                         d.basis_scale = b["c"]
                     else:
                         kind = _SPLIT_KINDS[self.split_mfma]
-                        if kind and rows % 128 == 0 and cols % 128 == 0:
+                        if kind == 2 and rows % 128 == 0 and cols % 128 == 0:
                             sp, sc = self._split_of(n, P, kind)
                             d.proj_split, d.split_kind, d.split_scale = sp.data_ptr(), kind, sc
                 else:
@@ -349,15 +349,15 @@ class NSCLOptimizerBase(Optimizer):
         also keeps its address from being recycled while the copy is alive)."""
         c = self._splits.get(name)
         if c is None or c["P"] is not P or c["version"] != P._version or c["kind"] != kind:
-            split, scale = (ops.split_projector(P) if kind == 1 else ops.split_projector_f16(P)), 0.0
+            split, scale = ops.split_projector_f16(P), 0.0
             c = self._splits[name] = dict(P=P, version=P._version, kind=kind, split=split, scale=scale)
         return c["split"], c["scale"]
 
     def uses_split_mfma(self):
-        """The split kind every current plan runs its dense projection launch on: False, "bf16x3" or "f16x2"."""
+        """The split kind every current plan runs its dense projection launch on: False or "f16x2"."""
         lib = _lib.load_library()
         kinds = {lib.nsgp_plan_uses_split_mfma(p["handle"]) for p in self._plans}
-        return {1: "bf16x3", 2: "f16x2"}.get(kinds.pop(), False) if len(kinds) == 1 else False
+        return {2: "f16x2"}.get(kinds.pop(), False) if len(kinds) == 1 else False
 
     def plan_stats(self):
         """(gemm_flops, algorithmic_bytes, n_tiles, n_projected) summed over the current plans."""

@@ -182,6 +182,73 @@ def test_two_task_cycle_on_the_detector(N, dev):
         assert len(cov2) == 61
 
 
+def test_voc_10_10_step_with_16_image_batches(N, dev):
+    """configs[2] (VOC 10+10 task 2: split [0,10,20], 16 images per GPU -- voc_10_10_task2_2007.py:40 -- K <= 100 prototypes) on the
+    narrow R-50-FPN.  (i) B = 16 through the covariance hooks: the hooks take the BATCH MEAN of the activation before the unfold
+    (runner:908-913), so a 16-image batch gives one [L x D] operand -- checked on a 3x3 backbone conv, an FPN 3x3 and a strided 1x1
+    against the oracle's covariance of the very activations the hooks saw; (ii) one task-2 training step of that shape: teacher,
+    16-image student forward, the K = 100 bank on the fused replay path (4 row blocks), projected step -- finite losses, the fused
+    replay loss equal to the module path's."""
+    from nsgp_repre_amd.detection import DetSample, Instances, build_faster_rcnn
+    torch.manual_seed(5)
+    split, B, h, w = [0, 10, 20], 16, 128, 160
+    g = torch.Generator().manual_seed(50)
+
+    def batch(classes, seed):
+        g.manual_seed(seed)
+        x = torch.rand(B, 3, h, w, generator=g).to(dev)
+        samples = []
+        for i in range(B):
+            wh = torch.rand(3, 2, generator=g) * torch.tensor([w * 0.3, h * 0.3]) + 20
+            xy = torch.rand(3, 2, generator=g) * (torch.tensor([w, h]) - wh)
+            labels = (torch.arange(3) + 3 * i) % (classes[1] - classes[0]) + classes[0]
+            samples.append(DetSample(Instances(bboxes=torch.cat([xy, xy + wh], -1).to(dev), labels=labels.to(dev)), img_shape=(h, w)))
+        return x, samples
+    model = build_faster_rcnn(width=16, fc_out_channels=64, task_id=2, task_split=split).to(dev)
+    N.runner.nullspace.guard_conv_weights(model)
+    # (i) covariance hooks at B = 16
+    watch = {"backbone.layer2.0.conv2": None, "neck.fpn_convs.1.conv": None, "backbone.layer3.0.downsample.0": None}
+    mods = dict(model.named_modules())
+    hs = [mods[n].register_forward_hook(lambda m, i, o, n=n: watch.__setitem__(n, i[0].detach().float().cpu())) for n in watch]
+    ignore = N.runner.nullspace.full_ignore_keys(["rpn", "roi_head"])
+    cov = N.runner.cal_fea_in(model, [batch((0, 10), 1)], ignore, forward=lambda m, b: m(b[0], copy.deepcopy(b[1]), mode="nullspace"))
+    for h_ in hs:
+        h_.remove()
+    for n, x in watch.items():
+        assert x is not None and x.shape[0] == B
+        m = mods[n]
+        want = O.cov_conv2d(x, m.kernel_size, m.stride, m.padding)
+        got = cov[n + ".weight"].cpu()
+        assert (got - want).abs().max().item() <= 2e-5 * want.abs().max().item(), n
+    # (ii) one training step of the configs[2] shape
+    head = model.roi_head
+    K = 100
+    head.replay, head.task_split, head.task_id = True, split, 2
+    head.bbox_featss = torch.relu(torch.randn(K, 12544, device=dev))
+    head.tmp_label = torch.randint(0, 10, (K,), device=dev)
+    mix = N.runner.br_nullspace_runner.NullSpaceTaskMixin()
+    mix.task_id = 2
+    mix.attach_teacher(model)
+    opt = N.SGDNSCL(model.parameters(), lr=0.002, momentum=0.9, weight_decay=1e-4, svd=True)
+    N.runner.nullspace.wire_param_names(opt, model)
+    N.runner.update_optim_transforms(opt, {k: v for k, v in cov.items()}, ignore)
+    model.train()
+    x, samples = batch((10, 20), 2)
+    losses = model(x, copy.deepcopy(samples), mode="loss")
+    assert "replay_loss_cls" in losses and all(bool(torch.isfinite(v)) for v in losses.values())
+    assert head._fused_replay_operands() is not None
+    head.fused_replay = False
+    ref = head.add_replay_loss({})["replay_loss_cls"]
+    head.fused_replay = True
+    assert abs(losses["replay_loss_cls"].item() - ref.item()) <= 2e-6 * abs(ref.item())
+    sum(v for k, v in losses.items() if "loss" in k).backward()
+    opt.step()
+    torch.cuda.synchronize()
+    assert opt.lowrank_stats()[0] + opt.tile_counts()[0] + opt.tile_counts()[1] + opt.tile_counts()[2] > 0
+    assert all(bool(torch.isfinite(p).all()) for p in model.parameters())
+    opt.close()
+
+
 def test_segment_final_conv_weight_is_relocated(N, dev):
     """The harness guard against the MIOpen over-read that aborted round 1 (profiles/README.md, incident analysis): rebuild the
     dangerous layout on purpose -- a 512-byte 1x1 conv weight as the last block of a full 2 MiB segment with nothing mapped behind

@@ -140,7 +140,7 @@ def test_g1_steps_with_golden_projectors(N, dev, golden_dir, kind):
                 assert _rel(st[sk], g[f"{sk}__{_key(n)}"]) <= 1e-6, (kind, n, sk)
 
 
-@pytest.mark.parametrize("split", [False, "bf16x3", "f16x2"])
+@pytest.mark.parametrize("split", [False, "f16x2"])
 @pytest.mark.parametrize("kind", list(I.G1B_KINDS))
 def test_g1b_aligned_goldens_per_row(N, dev, golden_dir, kind, split):
     """The reference's own output on 128-aligned layers (G1b) against the kernels the bench times: the whole-tile fp32-MFMA
@@ -485,7 +485,7 @@ def _table_projectors(dev, layers):
     return cache
 
 
-@pytest.mark.parametrize("split", [False, "bf16x3", "f16x2"])
+@pytest.mark.parametrize("split", [False, "f16x2"])
 @pytest.mark.parametrize("depth", [50, 101])
 def test_full_table_one_step_vs_oracle_per_row(N, dev, depth, split):
     """The complete projected-layer table of R-50-FPN (BASELINE configs[1]: 50 layers, 118.3 GFLOP) and R-101-FPN (configs[4]:
@@ -956,21 +956,8 @@ def _proj_for(shapes, names):
     return tr
 
 
-# ------------------------------------------------------------------ three-term bf16 split of the projection GEMM
-def test_split_projector_terms_sum_to_the_projector(N, dev):
-    from nsgp_repre_amd import ops
-    g = torch.Generator().manual_seed(3)
-    for D in (128, 256, 1152):
-        P = (torch.randn(D, D, generator=g) * torch.logspace(0, -6, D)[None, :]).to(dev)     # 6 decades of magnitudes
-        sp = ops.split_projector(P).view(D, D // 8, 3, 8).float()                            # [n][k/8][term][8]
-        terms = sp.permute(2, 0, 1, 3).reshape(3, D, D)                                        # [term][n][k]
-        back = (terms[0].double() + terms[1].double() + terms[2].double()).t()                 # [k][n] = P
-        err = (back - P.double()).abs()
-        assert (err <= 2.0 ** -23 * P.double().abs() + 1e-45).all()                            # 3 x 8 mantissa bits
-        assert (terms[1].abs() <= 2.0 ** -8 * terms[0].abs() + 1e-38).all()                    # each term is a residual of the last
-
-
-@pytest.mark.parametrize("split", ["bf16x3", "f16x2"])
+# ------------------------------------------------------------------ two-term fp16 split of the projection GEMM
+@pytest.mark.parametrize("split", ["f16x2"])
 @pytest.mark.parametrize("kind", ["sgd", "sgd_nomomentum", "sgd_nesterov", "adamw", "adam_amsgrad"])
 def test_split_mfma_steps_vs_oracle(N, dev, kind, split):
     """Both split projection paths against the CPU oracle under the same 1e-5 gate as the fp32 path: aligned layers run
@@ -996,7 +983,7 @@ def test_split_mfma_steps_vs_oracle(N, dev, kind, split):
         assert (params[n] - params2[n]).abs().max().item() <= REL * upd + 4 * 2.0 ** -23 * cpu[n].abs().max().item(), n
 
 
-@pytest.mark.parametrize("split", ["bf16x3", "f16x2"])
+@pytest.mark.parametrize("split", ["f16x2"])
 def test_split_mfma_with_misaligned_gradients_and_projector_edits(N, dev, split):
     """(i) gradient views at odd offsets: the bf16 kernel's tile falls back to the guarded fp32 loader for that operand, the
     fp16 path reads them with scalar loads in the elementwise launch that writes the split copy;
@@ -1274,7 +1261,7 @@ def test_state_dict_round_trip_keeps_stepping_correctly(N, dev):
 
 
 # ------------------------------------------------------------------ projector caches keyed on identity, explicit teardown
-@pytest.mark.parametrize("split", ["f16x2", "bf16x3", False, "low_rank"])
+@pytest.mark.parametrize("split", ["f16x2", False, "low_rank"])
 def test_rebuilding_projectors_on_a_stepped_optimizer(N, dev, split):
     """Task t -> t+1 inside one process: ``get_eigens`` / ``get_transforms`` run again on an optimizer that has already
     stepped.  ``set_basis`` frees the old projector of a layer just before the next layer's is allocated, so with several

@@ -4,7 +4,7 @@
 # The counter passes are restricted to this library's kernels (--kernel-include-regex): with counters on every dispatch rocprofv3
 # aborts inside rocSOLVER's syevd, which bench.py now runs to make the projectors (SURVEY 8d pipeline).
 set -o pipefail
-TAG=${1:-r02}
+TAG=${1:-r03}
 OUT=gpurun_out/prof_$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp

@@ -17,7 +17,8 @@ OURS = ("nsgp_", "repre_", "nsgp::")
 
 def short(name):
     for key in ("nsgp_project_v2_kernel", "nsgp_update_lr_kernel", "nsgp_lr_apply_kernel", "nsgp_lr_reduce_kernel", "nsgp_projector_head_kernel", "nsgp_project_kernel", "nsgp_update_kernel", "nsgp_project_single_kernel", "nsgp_projector_kernel",
-                "nsgp_cov_syrk_kernel", "nsgp_cov_reduce_kernel", "nsgp_batch_mean_pad_kernel", "repre_sim_mask_kernel",
+                "rh_skinny_kernel", "rh_reduce_kernel", "rh_scores_kernel", "rh_dz_kernel", "rh_tn_kernel", "repre_replay_ce_fwd_kernel", "repre_replay_ce_bwd_kernel",
+                "nsgp_cov_syrk_v2_kernel", "nsgp_cov_reduce_v2_kernel", "nsgp_cov_im2col_split_kernel", "nsgp_cov_syrk_kernel", "nsgp_cov_reduce_kernel", "nsgp_batch_mean_pad_kernel", "repre_sim_mask_kernel",
                 "repre_row_norm_kernel", "repre_masked_sum_kernel"):
         if key in name:
             tail = name[name.find(key):]
