@@ -86,7 +86,12 @@ constexpr int CHUNK = 4096;   // elements per workgroup of the elementwise kerne
                               // load -> store rounds; the kernel gets its bandwidth from the number of workgroups in flight, and with 16,384-element
                               // chunks the 14.6 M un-projected elements of R-50-FPN were 3.5 workgroups per CU: 2.5 TB/s.)
 constexpr int NSLOT = 4;      // depth of the per-step upload ring
-constexpr int PROF_EV = 6;    // events per profiled step
+// events per profiled step: start, after the plain launch, after the dense launches, 3 per low-rank group (nsgp_plan::prof_per_step)
+// Cache blocking of the low-rank launches (layers cut into G groups whose (update, p) working set fits the 256 MB memory-side cache,
+// fused -> reduce -> apply issued group by group) was measured and NOT kept: every extra group costs ~17 us in the fused launch and
+// ~10 us in the apply launch (launch boundary: tail + ramp) and the apply launch gets no faster -- 0.28 / 0.31 / 0.35 / 0.36 / 0.41 ms
+// per R-50 step at G = 1 / 2 / 3 / 4 / 6 (profiles/r03/lr_groups_study.log).  The group tables stay (one group).
+constexpr int g_lr_groups = 1;
 
 struct DynBlock {  // uploaded every step: hyper sets + current grad pointers
     nsgp_hyper_t hyper[NSGP_MAX_HYPER];
@@ -730,6 +735,11 @@ struct nsgp_plan {
     TileDev* d_tiles = nullptr;  // dense fast tiles | dense generic tiles | low-rank phase-1 | phase-2
     int n_tiles_lr1 = 0, n_tiles_lr2 = 0, n_lowrank = 0;    // low-rank: workgroups of the fused update + T launches and of the apply launch
     int n_chunks_lr = 0;
+    // cache blocking of the low-rank launches: the layers are cut into groups whose (update, p) working set fits the 256 MB
+    // Infinity Cache, and fused -> reduce -> apply run group by group, so that the apply launch's re-read of the update and of p
+    // (8 of its 12 bytes per element) is served by the memory-side cache instead of HBM.  Offsets / counts into d_tiles, d_chunks_lr.
+    struct LrGroup { int lr1_off, lr1_n, lr2_off, lr2_n, chunk_off, chunk_n; };
+    std::vector<LrGroup> lr_groups;
     ChunkDev* d_chunks_lr = nullptr;
     double lowrank_flops = 0;
     ChunkDev* d_chunks = nullptr;
@@ -739,10 +749,10 @@ struct nsgp_plan {
     hipEvent_t ev[NSLOT] = {nullptr, nullptr, nullptr, nullptr};
     bool ev_used[NSLOT] = {false, false, false, false};
     int slot = 0;
-    // optional per-launch timing: PROF_EV events per recorded step (before the elementwise launch, after it, after the fused
-    // update + T launch of the low-rank layers, after the dense GEMM launches, after the slab reduce, after the low-rank apply launch)
+    // optional per-launch timing: prof_per_step events per recorded step (before the elementwise launch, after it, after the dense
+    // GEMM launches, and per low-rank group after its fused update + T launch, its slab reduce and its apply launch)
     std::vector<hipEvent_t> prof_ev;
-    int prof_cap = 0, prof_n = 0;
+    int prof_cap = 0, prof_n = 0, prof_per_step = 0;
     float prof_detail[5] = {0, 0, 0, 0, 0};   // averages of the last profile_end: elementwise, fused update + T, dense GEMM, slab reduce, low-rank apply
 };
 
@@ -957,6 +967,7 @@ extern "C" int nsgp_plan_create(nsgp_plan_t** out, const nsgp_tensor_t* tensors,
     // spread).  Layers in descending cost order.
     std::vector<TileDev> lr1, lr2;
     std::vector<ChunkDev> lr_chunks;      // slab reduce of the layers with more than one K range
+    std::vector<nsgp_plan::LrGroup> lr_group_recs;
     {
         std::vector<int> lo;
         for (size_t li = 0; li < ld.size(); ++li)
@@ -986,27 +997,52 @@ extern "C" int nsgp_plan_create(nsgp_plan_t** out, const nsgp_tensor_t* tensors,
         };
         auto t_cost = [&](int li) { return (long)ld[li].cols * ld[li].rpad / ld[li].nsplit; };
         std::stable_sort(lo.begin(), lo.end(), [&](int a, int b) { return t_cost(a) > t_cost(b); });
+        // layer groups (cache blocking, see nsgp_plan::lr_groups): contiguous runs of the cost-sorted layer list with about equal
+        // element counts; one group = today's three launches
+        const int G = std::max(1, std::min(std::min(16, g_lr_groups), (int)std::max<size_t>(1, lo.size())));
+        double total_el = 0;
+        for (int li : lo) total_el += (double)ld[li].rows * ld[li].cols;
+        std::vector<std::vector<int>> groups(G);
         {
-            std::vector<TileDev> q[8];
-            for (int li : lo)
-                for (int sp = 0; sp < ld[li].nsplit; ++sp) {
-                    std::vector<TileDev>& dq = q[shortest(q)];
-                    for (int m = 0; m < ld[li].rows; m += 32) dq.push_back(TileDev{li, m, 0, sp});
-                }
-            xcd_interleave(q, lr1);
+            double seen = 0;
+            for (int li : lo) {
+                const int gi = std::min(G - 1, (int)(seen * G / std::max(total_el, 1.0)));
+                groups[gi].push_back(li);
+                seen += (double)ld[li].rows * ld[li].cols;
+            }
         }
-        for (int li : lo)
-            if (ld[li].nsplit > 1)
-                for (long st = 0; st < (long)ld[li].rows * ld[li].rpad; st += LR_REDUCE_CHUNK) lr_chunks.push_back(ChunkDev{li, 0, st});
-        std::stable_sort(lo.begin(), lo.end(), [&](int a, int b) { return ld[a].rpad > ld[b].rpad; });
-        {
-            std::vector<TileDev> q[8];
-            for (int li : lo)
-                for (int n0 = 0; n0 < ld[li].cols; n0 += LRA_COLS) {
-                    std::vector<TileDev>& dq = q[shortest(q)];
-                    for (int m = 0; m < ld[li].rows; m += 32) dq.push_back(TileDev{li, m, n0, std::min(LRA_COLS, ld[li].cols - n0)});
-                }
-            xcd_interleave(q, lr2);
+        for (auto& grp : groups) {
+            if (grp.empty()) continue;
+            nsgp_plan::LrGroup rec{(int)lr1.size(), 0, (int)lr2.size(), 0, (int)lr_chunks.size(), 0};
+            {
+                std::vector<TileDev> q[8], part;
+                for (int li : grp)
+                    for (int sp = 0; sp < ld[li].nsplit; ++sp) {
+                        std::vector<TileDev>& dq = q[shortest(q)];
+                        for (int m = 0; m < ld[li].rows; m += 32) dq.push_back(TileDev{li, m, 0, sp});
+                    }
+                xcd_interleave(q, part);
+                lr1.insert(lr1.end(), part.begin(), part.end());
+            }
+            for (int li : grp)
+                if (ld[li].nsplit > 1)
+                    for (long st = 0; st < (long)ld[li].rows * ld[li].rpad; st += LR_REDUCE_CHUNK) lr_chunks.push_back(ChunkDev{li, 0, st});
+            std::vector<int> by_rpad(grp);
+            std::stable_sort(by_rpad.begin(), by_rpad.end(), [&](int a, int b) { return ld[a].rpad > ld[b].rpad; });
+            {
+                std::vector<TileDev> q[8], part;
+                for (int li : by_rpad)
+                    for (int n0 = 0; n0 < ld[li].cols; n0 += LRA_COLS) {
+                        std::vector<TileDev>& dq = q[shortest(q)];
+                        for (int m = 0; m < ld[li].rows; m += 32) dq.push_back(TileDev{li, m, n0, std::min(LRA_COLS, ld[li].cols - n0)});
+                    }
+                xcd_interleave(q, part);
+                lr2.insert(lr2.end(), part.begin(), part.end());
+            }
+            rec.lr1_n = (int)lr1.size() - rec.lr1_off;
+            rec.lr2_n = (int)lr2.size() - rec.lr2_off;
+            rec.chunk_n = (int)lr_chunks.size() - rec.chunk_off;
+            lr_group_recs.push_back(rec);
         }
     }
     std::vector<TileDev> all_tiles(fast_tiles);
@@ -1017,6 +1053,8 @@ extern "C" int nsgp_plan_create(nsgp_plan_t** out, const nsgp_tensor_t* tensors,
     P->n_tiles_lr1 = (int)lr1.size();
     P->n_tiles_lr2 = (int)lr2.size();
     P->n_chunks_lr = (int)lr_chunks.size();
+    P->lr_groups = lr_group_recs;
+    P->prof_per_step = 3 + 3 * (int)lr_group_recs.size();
     P->n_lowrank = n_lowrank;
     P->lowrank_flops = lr_flops;
     P->dyn_bytes = (sizeof(nsgp_hyper_t) * NSGP_MAX_HYPER + sizeof(float*) * (size_t)n + 255) & ~(size_t)255;
@@ -1154,7 +1192,9 @@ extern "C" int nsgp_plan_step(nsgp_plan_t* P, float* const* grads, const nsgp_hy
     NSGP_HIP(hipMemcpyAsync(P->d_dyn[s], P->h_dyn[s], P->dyn_bytes, hipMemcpyHostToDevice, stream));
     const DynBlock* d = reinterpret_cast<const DynBlock*>(P->d_dyn[s]);
     const bool prof = P->prof_n < P->prof_cap;
-    if (prof) NSGP_HIP(hipEventRecord(P->prof_ev[PROF_EV * P->prof_n + 0], stream));
+    hipEvent_t* pe = prof ? &P->prof_ev[(size_t)P->prof_per_step * P->prof_n] : nullptr;
+    int ei = 0;
+    if (prof) NSGP_HIP(hipEventRecord(pe[ei++], stream));
 
     if (P->n_chunks > 0) {
         if (P->optimizer == NSGP_OPT_SGD)
@@ -1163,16 +1203,8 @@ extern "C" int nsgp_plan_step(nsgp_plan_t* P, float* const* grads, const nsgp_hy
             hipLaunchKernelGGL(nsgp_update_kernel<NSGP_OPT_ADAM>, dim3(P->n_chunks), dim3(256), 0, stream, P->d_chunks, P->d_tensors, d);
         NSGP_LAUNCH_CHECK();
     }
-    if (prof) NSGP_HIP(hipEventRecord(P->prof_ev[PROF_EV * P->prof_n + 1], stream));
-    if (P->n_tiles_lr1 > 0) {      // low-rank layers: their update, fused with T = u U
-        const TileDev* t1 = P->d_tiles + P->n_tiles_fast + P->n_tiles_generic;
-        if (P->optimizer == NSGP_OPT_SGD)
-            hipLaunchKernelGGL(nsgp_update_lr_kernel<NSGP_OPT_SGD>, dim3(P->n_tiles_lr1), dim3(256), 0, stream, t1, P->d_layers, P->d_tensors, d);
-        else
-            hipLaunchKernelGGL(nsgp_update_lr_kernel<NSGP_OPT_ADAM>, dim3(P->n_tiles_lr1), dim3(256), 0, stream, t1, P->d_layers, P->d_tensors, d);
-        NSGP_LAUNCH_CHECK();
-    }
-    if (prof) NSGP_HIP(hipEventRecord(P->prof_ev[PROF_EV * P->prof_n + 2], stream));
+    if (prof) NSGP_HIP(hipEventRecord(pe[ei++], stream));
+    // dense projection of the layers that are not on the low-rank form (their update was written by the launch above)
     if (P->n_tiles_v2 > 0) {
         const TileDev* vt = P->d_tiles + P->n_tiles_fast + P->n_tiles_generic + P->n_tiles_lr1 + P->n_tiles_lr2;
         if (P->optimizer == NSGP_OPT_SGD)
@@ -1196,25 +1228,30 @@ extern "C" int nsgp_plan_step(nsgp_plan_t* P, float* const* grads, const nsgp_hy
             hipLaunchKernelGGL((nsgp_project_kernel<NSGP_OPT_ADAM, false>), dim3(P->n_tiles_generic), dim3(THREADS), SMEM_BYTES, stream, gt, P->d_layers, d);
         NSGP_LAUNCH_CHECK();
     }
-    if (prof) NSGP_HIP(hipEventRecord(P->prof_ev[PROF_EV * P->prof_n + 3], stream));
-    if (P->n_tiles_lr1 > 0) {
-        const TileDev* t2 = P->d_tiles + P->n_tiles_fast + P->n_tiles_generic + P->n_tiles_lr1;
-        if (P->n_chunks_lr > 0) {
-            hipLaunchKernelGGL(nsgp_lr_reduce_kernel, dim3(P->n_chunks_lr), dim3(256), 0, stream, P->d_chunks_lr, P->d_layers, d, P->optimizer);
+    if (prof) NSGP_HIP(hipEventRecord(pe[ei++], stream));
+    // low-rank layers, group by group: update fused with T = u U -> ordered slab reduce -> apply
+    const TileDev* t1 = P->d_tiles + P->n_tiles_fast + P->n_tiles_generic;
+    const TileDev* t2 = t1 + P->n_tiles_lr1;
+    for (const nsgp_plan::LrGroup& g : P->lr_groups) {
+        if (P->optimizer == NSGP_OPT_SGD)
+            hipLaunchKernelGGL(nsgp_update_lr_kernel<NSGP_OPT_SGD>, dim3(g.lr1_n), dim3(256), 0, stream, t1 + g.lr1_off, P->d_layers, P->d_tensors, d);
+        else
+            hipLaunchKernelGGL(nsgp_update_lr_kernel<NSGP_OPT_ADAM>, dim3(g.lr1_n), dim3(256), 0, stream, t1 + g.lr1_off, P->d_layers, P->d_tensors, d);
+        NSGP_LAUNCH_CHECK();
+        if (prof) NSGP_HIP(hipEventRecord(pe[ei++], stream));
+        if (g.chunk_n > 0) {
+            hipLaunchKernelGGL(nsgp_lr_reduce_kernel, dim3(g.chunk_n), dim3(256), 0, stream, P->d_chunks_lr + g.chunk_off, P->d_layers, d, P->optimizer);
             NSGP_LAUNCH_CHECK();
         }
-        if (prof) NSGP_HIP(hipEventRecord(P->prof_ev[PROF_EV * P->prof_n + 4], stream));
+        if (prof) NSGP_HIP(hipEventRecord(pe[ei++], stream));
         if (P->optimizer == NSGP_OPT_SGD)
-            hipLaunchKernelGGL(nsgp_lr_apply_kernel<NSGP_OPT_SGD>, dim3(P->n_tiles_lr2), dim3(256), 0, stream, t2, P->d_layers, d);
+            hipLaunchKernelGGL(nsgp_lr_apply_kernel<NSGP_OPT_SGD>, dim3(g.lr2_n), dim3(256), 0, stream, t2 + g.lr2_off, P->d_layers, d);
         else
-            hipLaunchKernelGGL(nsgp_lr_apply_kernel<NSGP_OPT_ADAM>, dim3(P->n_tiles_lr2), dim3(256), 0, stream, t2, P->d_layers, d);
+            hipLaunchKernelGGL(nsgp_lr_apply_kernel<NSGP_OPT_ADAM>, dim3(g.lr2_n), dim3(256), 0, stream, t2 + g.lr2_off, P->d_layers, d);
         NSGP_LAUNCH_CHECK();
+        if (prof) NSGP_HIP(hipEventRecord(pe[ei++], stream));
     }
-    if (prof) {
-        if (P->n_tiles_lr1 == 0) NSGP_HIP(hipEventRecord(P->prof_ev[PROF_EV * P->prof_n + 4], stream));
-        NSGP_HIP(hipEventRecord(P->prof_ev[PROF_EV * P->prof_n + 5], stream));
-        ++P->prof_n;
-    }
+    if (prof) ++P->prof_n;
     NSGP_HIP(hipEventRecord(P->ev[s], stream));
     P->ev_used[s] = true;
     return NSGP_OK;
@@ -1222,7 +1259,7 @@ extern "C" int nsgp_plan_step(nsgp_plan_t* P, float* const* grads, const nsgp_hy
 
 extern "C" int nsgp_plan_profile_begin(nsgp_plan_t* P, int max_steps) {
     if (!P || max_steps < 0 || max_steps > 4096) return fail(NSGP_ERR_INVALID, "nsgp_plan_profile_begin: bad argument");
-    while ((int)P->prof_ev.size() < PROF_EV * max_steps) {
+    while ((int)P->prof_ev.size() < P->prof_per_step * max_steps) {
         hipEvent_t e;
         NSGP_HIP(hipEventCreate(&e));
         P->prof_ev.push_back(e);
@@ -1234,24 +1271,34 @@ extern "C" int nsgp_plan_profile_begin(nsgp_plan_t* P, int max_steps) {
 
 extern "C" int nsgp_plan_profile_end(nsgp_plan_t* P, int* n_steps, float* update_ms_avg, float* gemm_ms_avg) {
     if (!P) return fail(NSGP_ERR_INVALID, "nsgp_plan_profile_end: null plan");
-    // update_ms = both elementwise launches (the multi-tensor kernel + the fused update + T kernel of the low-rank layers);
-    // gemm_ms = everything behind them (dense GEMM launches, slab reduce, low-rank apply)
-    double u = 0, g = 0, det[5] = {0, 0, 0, 0, 0};
+    // per step: e[0] start, e[1] after the plain launch, e[2] after the dense launches, then per low-rank group: after the fused
+    // update + T launch, after the slab reduce, after the apply launch.
+    // detail: [0] plain launch, [1] fused launches, [2] dense GEMM, [3] slab reduces, [4] apply launches (summed over the groups);
+    // update_ms = [0] + [1], gemm_ms = the rest
+    double det[5] = {0, 0, 0, 0, 0};
+    const int G = (int)P->lr_groups.size();
     for (int i = 0; i < P->prof_n; ++i) {
-        hipEvent_t* e = &P->prof_ev[PROF_EV * i];
-        NSGP_HIP(hipEventSynchronize(e[5]));
-        float a = 0, b = 0, d5[5] = {0, 0, 0, 0, 0};
-        NSGP_HIP(hipEventElapsedTime(&a, e[0], e[2]));
-        NSGP_HIP(hipEventElapsedTime(&b, e[2], e[5]));
-        for (int k = 0; k < 5; ++k) NSGP_HIP(hipEventElapsedTime(&d5[k], e[k], e[k + 1]));
-        u += a;
-        g += b;
-        for (int k = 0; k < 5; ++k) det[k] += d5[k];
+        hipEvent_t* e = &P->prof_ev[(size_t)P->prof_per_step * i];
+        NSGP_HIP(hipEventSynchronize(e[P->prof_per_step - 1]));
+        float ms = 0;
+        NSGP_HIP(hipEventElapsedTime(&ms, e[0], e[1]));
+        det[0] += ms;
+        NSGP_HIP(hipEventElapsedTime(&ms, e[1], e[2]));
+        det[2] += ms;
+        for (int g = 0; g < G; ++g) {
+            hipEvent_t* ge = e + 2 + 3 * g;
+            NSGP_HIP(hipEventElapsedTime(&ms, ge[0], ge[1]));
+            det[1] += ms;
+            NSGP_HIP(hipEventElapsedTime(&ms, ge[1], ge[2]));
+            det[3] += ms;
+            NSGP_HIP(hipEventElapsedTime(&ms, ge[2], ge[3]));
+            det[4] += ms;
+        }
     }
     for (int k = 0; k < 5; ++k) P->prof_detail[k] = P->prof_n ? (float)(det[k] / P->prof_n) : 0.0f;
     if (n_steps) *n_steps = P->prof_n;
-    if (update_ms_avg) *update_ms_avg = P->prof_n ? (float)(u / P->prof_n) : 0.0f;
-    if (gemm_ms_avg) *gemm_ms_avg = P->prof_n ? (float)(g / P->prof_n) : 0.0f;
+    if (update_ms_avg) *update_ms_avg = P->prof_detail[0] + P->prof_detail[1];
+    if (gemm_ms_avg) *gemm_ms_avg = P->prof_detail[2] + P->prof_detail[3] + P->prof_detail[4];
     P->prof_cap = 0;
     P->prof_n = 0;
     return NSGP_OK;

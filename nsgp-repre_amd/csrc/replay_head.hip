@@ -28,6 +28,7 @@
 
 #include "common.hpp"
 #include "gemm_core.hpp"
+#include "replay_ce.hpp"
 
 namespace nsgp {
 
@@ -174,7 +175,7 @@ __global__ __launch_bounds__(256, 2) void rh_skinny_kernel(const RhGemm g) {
     }
 }
 
-// H[m][n] = relu(bias[n] + sum_s slab[s][m][n]), ranges summed in order
+// H[m][n] = relu(bias[n] + sum_s slab[s][m][n]), ranges summed in order (loads of eight ranges in flight together)
 template <bool VEC>
 __global__ __launch_bounds__(256) void rh_reduce_kernel(const float* __restrict__ slabs, int S, int Mpad, int M, int N, const float* __restrict__ bias,
                                                         float* __restrict__ out) {
@@ -185,7 +186,15 @@ __global__ __launch_bounds__(256) void rh_reduce_kernel(const float* __restrict_
         const long i = i4 * 4;
         const int n = (int)(i % N);
         f32x4 sum = *(const gf32x4*)(slabs + i);
-        for (int s = 1; s < S; ++s) sum += *(const gf32x4*)(slabs + s * stride + i);
+        int s = 1;
+        for (; s + 8 <= S; s += 8) {
+            f32x4 v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = *(const gf32x4*)(slabs + (s + u) * stride + i);
+#pragma unroll
+            for (int u = 0; u < 8; ++u) sum += v[u];
+        }
+        for (; s < S; ++s) sum += *(const gf32x4*)(slabs + s * stride + i);
         const f32x4 b = *(const gf32x4*)(bias + n);
         f32x4 o;
 #pragma unroll
@@ -200,51 +209,75 @@ __global__ __launch_bounds__(256) void rh_reduce_kernel(const float* __restrict_
     }
 }
 
-__device__ __forceinline__ float rh_wave_sum(float v) {
-    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
-    return v;
-}
-
-// scores[m][c] = bc[c] + sum_k H[m][k] Wc[c][k]: one wave per row, the row held in registers (hidden <= 64 * 4 * RH_HREG)
-constexpr int RH_HREG = 8;
+// scores[m][c] = bc[c] + sum_k H[m][k] Wc[c][k] for 8 rows per workgroup (thread = (row, class), H and Wc staged through LDS in
+// 256-wide k chunks, Wc rows padded to 257 floats: conflict-free), then the rows' double-softmax CE terms
+// rowloss[m] = logsumexp(softmax(s_m)) - softmax(s_m)[y_m]  (head:499) from the scores still in LDS, one wave per two rows.
+constexpr int RS_ROWS = 8, RS_KC = 256, RS_WLD = RS_KC + 1;
 __global__ __launch_bounds__(256) void rh_scores_kernel(const float* __restrict__ H, int M, int hidden, const float* __restrict__ Wc,
-                                                        const float* __restrict__ bc, int C, float* __restrict__ scores) {
-    const int lane = threadIdx.x & 63, m = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (m >= M) return;
-    const bool vec = (hidden & 3) == 0;
-    if (vec && hidden <= 256 * RH_HREG) {
-        f32x4 h[RH_HREG];
+                                                        const float* __restrict__ bc, int C, const long long* __restrict__ labels,
+                                                        float* __restrict__ scores, float* __restrict__ rowloss) {
+    __shared__ float Hs[RS_ROWS * RS_KC];
+    __shared__ float Ws[32 * RS_WLD];
+    __shared__ float sc[RS_ROWS * RH_MAX_COLS];
+    const int t = threadIdx.x, r = t >> 5, c = t & 31, m0 = blockIdx.x * RS_ROWS;
+    for (int c0 = 0; c0 < C; c0 += 32) {
+        float acc = 0.0f;
+        for (int k0 = 0; k0 < hidden; k0 += RS_KC) {
+            __syncthreads();
 #pragma unroll
-        for (int i = 0; i < RH_HREG; ++i) {
-            const int k = 4 * lane + 256 * i;
-            h[i] = (k < hidden) ? *(const gf32x4*)(H + (long)m * hidden + k) : f32x4{0, 0, 0, 0};
-        }
-        for (int c = 0; c < C; ++c) {
-            float dot = 0.0f;
-#pragma unroll
-            for (int i = 0; i < RH_HREG; ++i) {
-                const int k = 4 * lane + 256 * i;
-                if (k < hidden) {
-                    const f32x4 w = *(const gf32x4*)(Wc + (long)c * hidden + k);
-                    dot += h[i][0] * w[0] + h[i][1] * w[1] + h[i][2] * w[2] + h[i][3] * w[3];
-                }
+            for (int i = 0; i < RS_ROWS; ++i) {
+                const int idx = t + 256 * i, rr = idx >> 8, kk = idx & 255;
+                Hs[idx] = (m0 + rr < M && k0 + kk < hidden) ? H[(long)(m0 + rr) * hidden + k0 + kk] : 0.0f;
             }
-            dot = rh_wave_sum(dot);
-            if (lane == 0) scores[(long)m * C + c] = dot + bc[c];
+#pragma unroll 8
+            for (int i = 0; i < 32; ++i) {
+                const int idx = t + 256 * i, cc = idx >> 8, kk = idx & 255;
+                Ws[cc * RS_WLD + kk] = (c0 + cc < C && k0 + kk < hidden) ? Wc[(long)(c0 + cc) * hidden + k0 + kk] : 0.0f;
+            }
+            __syncthreads();
+#pragma unroll 8
+            for (int kk = 0; kk < RS_KC; ++kk) acc += Hs[r * RS_KC + kk] * Ws[c * RS_WLD + kk];
         }
-    } else {
-        for (int c = 0; c < C; ++c) {
-            float dot = 0.0f;
-            for (int k = lane; k < hidden; k += 64) dot += H[(long)m * hidden + k] * Wc[(long)c * hidden + k];
-            dot = rh_wave_sum(dot);
-            if (lane == 0) scores[(long)m * C + c] = dot + bc[c];
+        if (c0 + c < C) {
+            const float v = acc + bc[c0 + c];
+            sc[r * RH_MAX_COLS + c0 + c] = v;
+            if (m0 + r < M) scores[(long)(m0 + r) * C + c0 + c] = v;
         }
+    }
+    __syncthreads();
+    const int lane = t & 63, wave = t >> 6;
+    for (int rr = 2 * wave; rr < 2 * wave + 2; ++rr) {
+        if (m0 + rr >= M) continue;                        // uniform per wave
+        float q[4];
+        const float lse = row_double_softmax(sc + rr * RH_MAX_COLS, C, lane, q);
+        const int y = (int)labels[m0 + rr];
+        float qy = 0.0f;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) if (lane + 64 * e == y) qy = q[e];
+        qy = wave_sum(qy);
+        if (lane == 0) rowloss[m0 + rr] = lse - qy;
     }
 }
 
-// dZ[m][n] = up[m][n] * (H[m][n] > 0) for a block of 32 columns and ALL rows; up = sum of slabs (MODE 0) or dS Wc (MODE 1).
-// Also: dZT[n][m] (zero-padded to Mp columns), db[n] = sum_m dZ[m][n] (row groups summed in order).  In MODE 1 one extra workgroup
-// writes dST [C x Mp] (zero-padded) and dbc = column sums of dS.
+// loss = mean of the row terms, fixed summation order
+__global__ __launch_bounds__(256) void rh_mean_kernel(const float* __restrict__ rowloss, int M, float* __restrict__ loss_out) {
+    __shared__ float part[256];
+    float s = 0.0f;
+    for (int m = threadIdx.x; m < M; m += 256) s += rowloss[m];
+    part[threadIdx.x] = s;
+    __syncthreads();
+    for (int w = 128; w > 0; w >>= 1) {
+        if ((int)threadIdx.x < w) part[threadIdx.x] += part[threadIdx.x + w];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) *loss_out = part[0] / (float)M;
+}
+
+// dZ[m][n] = up[m][n] * (H[m][n] > 0) for a block of 16 columns and ALL rows; up = the sum of the K-range slabs (MODE 0: dZ2 W2)
+// or dS Wc (MODE 1).  Outputs: dZ (optional), dZT[n][m] (zero-padded to Mp columns: the A operand of the weight-gradient GEMM),
+// db[n] = sum_m dZ[m][n] (row groups summed in order).  MODE 1 also produces the class heads' gradients for its columns,
+// dWc[c][n] = sum_m dS[m][c] H[m][n] (rows in order, 64 at a time through LDS), and one extra workgroup writes dbc = column sums of dS.
+constexpr int DZ_COLS = 16, DZ_RC = 64, DZ_WACC = RH_MAX_COLS * DZ_COLS / 256;
 struct RhDz {
     const float* slabs; int S; int Mpad;         // MODE 0
     const float* dS; const float* Wc; int C;     // MODE 1
@@ -253,19 +286,15 @@ struct RhDz {
     float* dZ;                                   // [M x N] or null
     float* dZT;                                  // [N x Mp]
     float* db;                                   // [N]
-    float* dST; float* dbc;                      // MODE 1
+    float* dWc; float* dbc;                      // MODE 1: [C x N], [C]
 };
 
 template <int MODE>
 __global__ __launch_bounds__(256) void rh_dz_kernel(const RhDz a) {
-    extern __shared__ __attribute__((aligned(16))) float lds[];      // [32][Mp + 1] transposed tile | [8][32] partial sums | MODE 1: [C][32] Wc tile
+    extern __shared__ __attribute__((aligned(16))) float lds[];
     const int t = threadIdx.x;
-    const int nblocks = (a.N + 31) / 32;
-    if (MODE == 1 && (int)blockIdx.x == nblocks) {        // the extra workgroup: dS transposed + its column sums
-        for (int idx = t; idx < a.C * a.Mp; idx += 256) {
-            const int c = idx / a.Mp, m = idx - c * a.Mp;
-            a.dST[idx] = (m < a.M) ? a.dS[(long)m * a.C + c] : 0.0f;
-        }
+    const int nblocks = (a.N + DZ_COLS - 1) / DZ_COLS;
+    if (MODE == 1 && (int)blockIdx.x == nblocks) {        // the extra workgroup: column sums of dS
         for (int c = t; c < a.C; c += 256) {
             float s = 0.0f;
             for (int m = 0; m < a.M; ++m) s += a.dS[(long)m * a.C + c];
@@ -273,46 +302,87 @@ __global__ __launch_bounds__(256) void rh_dz_kernel(const RhDz a) {
         }
         return;
     }
-    const int c = t & 31, grp = t >> 5, n = blockIdx.x * 32 + c;
+    const int c = t & (DZ_COLS - 1), grp = t / DZ_COLS, n0 = blockIdx.x * DZ_COLS, n = n0 + c;
     const int TLD = a.Mp + 1;
-    float* tile = lds;
-    float* part = lds + 32 * TLD;
-    float* wct = part + 8 * 32;
+    float* tile = lds;                                   // [16][Mp + 1]
+    float* part = tile + DZ_COLS * TLD;                  // [16 groups][16]
+    float* wct = part + 16 * DZ_COLS;                    // MODE 1: [C][16]
+    float* dsc = wct + (MODE == 1 ? a.C * DZ_COLS : 0);  // MODE 1: [DZ_RC][C]
+    float* hc = dsc + (MODE == 1 ? DZ_RC * a.C : 0);     // MODE 1: [DZ_RC][16]
     if (MODE == 1) {
-        for (int idx = t; idx < a.C * 32; idx += 256) {
-            const int cc = idx >> 5, col = blockIdx.x * 32 + (idx & 31);
+        for (int idx = t; idx < a.C * DZ_COLS; idx += 256) {
+            const int cc = idx / DZ_COLS, col = n0 + (idx & (DZ_COLS - 1));
             wct[idx] = (col < a.N) ? a.Wc[(long)cc * a.N + col] : 0.0f;
         }
-        __syncthreads();
     }
     const long stride = (long)a.Mpad * a.N;
     float colsum = 0.0f;
-    for (int m = grp; m < a.M; m += 8) {
-        float v = 0.0f;
-        if (n < a.N) {
-            if (MODE == 0) {
-                v = a.slabs[(long)m * a.N + n];
-                for (int s = 1; s < a.S; ++s) v += a.slabs[s * stride + (long)m * a.N + n];
-            } else {
-                for (int cc = 0; cc < a.C; ++cc) v += a.dS[(long)m * a.C + cc] * wct[cc * 32 + c];
+    float wacc[DZ_WACC];
+#pragma unroll
+    for (int j = 0; j < DZ_WACC; ++j) wacc[j] = 0.0f;
+    for (int m0 = 0; m0 < a.M; m0 += DZ_RC) {
+        const int rows = min(DZ_RC, a.M - m0);
+        if (MODE == 1) {
+            __syncthreads();
+            for (int idx = t; idx < rows * a.C; idx += 256) dsc[idx] = a.dS[(long)m0 * a.C + idx];
+            for (int idx = t; idx < rows * DZ_COLS; idx += 256) {
+                const int rr = idx / DZ_COLS, col = n0 + (idx & (DZ_COLS - 1));
+                hc[idx] = (col < a.N) ? a.H[(long)(m0 + rr) * a.N + col] : 0.0f;
             }
-            v = (a.H[(long)m * a.N + n] > 0.0f) ? v : 0.0f;
-            if (a.dZ) a.dZ[(long)m * a.N + n] = v;
+            __syncthreads();
         }
-        tile[c * TLD + m] = v;
-        colsum += v;
+        for (int rr = grp; rr < rows; rr += 256 / DZ_COLS) {
+            const int m = m0 + rr;
+            float v = 0.0f;
+            if (n < a.N) {
+                float h;
+                if (MODE == 0) {
+                    v = a.slabs[(long)m * a.N + n];
+                    for (int s = 1; s < a.S; ++s) v += a.slabs[s * stride + (long)m * a.N + n];
+                    h = a.H[(long)m * a.N + n];
+                } else {
+                    for (int cc = 0; cc < a.C; ++cc) v += dsc[rr * a.C + cc] * wct[cc * DZ_COLS + c];
+                    h = hc[rr * DZ_COLS + c];
+                }
+                v = (h > 0.0f) ? v : 0.0f;
+                if (a.dZ) a.dZ[(long)m * a.N + n] = v;
+            }
+            tile[c * TLD + m] = v;
+            colsum += v;
+        }
+        if (MODE == 1) {
+#pragma unroll
+            for (int j = 0; j < DZ_WACC; ++j) {
+                const int idx = t + 256 * j;
+                if (idx < a.C * DZ_COLS) {
+                    const int cc = idx / DZ_COLS, nn = idx & (DZ_COLS - 1);
+                    float s = 0.0f;
+                    for (int rr = 0; rr < rows; ++rr) s += dsc[rr * a.C + cc] * hc[rr * DZ_COLS + nn];
+                    wacc[j] += s;
+                }
+            }
+        }
     }
-    part[grp * 32 + c] = colsum;
+    part[grp * DZ_COLS + c] = colsum;
     __syncthreads();
     if (grp == 0 && n < a.N) {
         float s = part[c];
-        for (int k = 1; k < 8; ++k) s += part[k * 32 + c];
+        for (int k = 1; k < 256 / DZ_COLS; ++k) s += part[k * DZ_COLS + c];
         a.db[n] = s;
     }
-    for (int idx = t; idx < 32 * a.Mp; idx += 256) {
+    for (int idx = t; idx < DZ_COLS * a.Mp; idx += 256) {
         const int cc = idx / a.Mp, m = idx - cc * a.Mp;
-        const int col = blockIdx.x * 32 + cc;
-        if (col < a.N) a.dZT[(long)col * a.Mp + m] = (m < a.M) ? tile[cc * TLD + m] : 0.0f;
+        if (n0 + cc < a.N) a.dZT[(long)(n0 + cc) * a.Mp + m] = (m < a.M) ? tile[cc * TLD + m] : 0.0f;
+    }
+    if (MODE == 1) {
+#pragma unroll
+        for (int j = 0; j < DZ_WACC; ++j) {
+            const int idx = t + 256 * j;
+            if (idx < a.C * DZ_COLS) {
+                const int cc = idx / DZ_COLS, col = n0 + (idx & (DZ_COLS - 1));
+                if (col < a.N) a.dWc[(long)cc * a.N + col] = wacc[j];
+            }
+        }
     }
 }
 
@@ -399,7 +469,7 @@ static RhPlan rh_plan(int M, int N, int K) {
     p.Mpad = p.mchunks * p.MB * 32;
     p.ntn = (N + 127) / 128;
     const int nk = (K + 31) / 32;
-    int S = std::max(1, std::min(nk, RH_TARGET_WGS / std::max(1, p.ntn * p.mchunks)));
+    int S = std::max(1, std::min(std::max(1, nk / 4), RH_TARGET_WGS / std::max(1, p.ntn * p.mchunks)));     // >= 4 k-steps per range
     p.per = (nk + S - 1) / S;
     p.S = (nk + p.per - 1) / p.per;
     p.grid = 8 * p.ntn * p.mchunks * ((p.S + 7) / 8);
@@ -409,7 +479,7 @@ static RhPlan rh_plan(int M, int N, int K) {
 static size_t rh_pad(size_t x) { return (x + 255) & ~(size_t)255; }
 
 struct RhWorkspace {
-    size_t slabs, dS, dST, dZ2, dZ2T, dZ1T, total;
+    size_t slabs, dS, rowloss, dZ2, dZ2T, dZ1T, total;
 };
 
 static RhWorkspace rh_workspace(int M, int in_f, int hidden, int C) {
@@ -420,7 +490,7 @@ static RhWorkspace rh_workspace(int M, int in_f, int hidden, int C) {
     size_t off = 0;
     w.slabs = off; off += rh_pad(slab_f);
     w.dS = off; off += rh_pad((size_t)M * C * 4);
-    w.dST = off; off += rh_pad((size_t)C * Mp * 4);
+    w.rowloss = off; off += rh_pad((size_t)M * 4);
     w.dZ2 = off; off += rh_pad((size_t)M * hidden * 4);
     w.dZ2T = off; off += rh_pad((size_t)hidden * Mp * 4);
     w.dZ1T = off; off += rh_pad((size_t)hidden * Mp * 4);
@@ -431,11 +501,18 @@ static RhWorkspace rh_workspace(int M, int in_f, int hidden, int C) {
 template <int MB, bool B_ROWS>
 static int rh_launch_skinny_mb(const RhGemm& g, const RhPlan& p, bool fast, hipStream_t stream) {
     const size_t smem = (size_t)rh_smem_floats<MB>() * 4;
+    static bool armed[2] = {false, false};       // the LDS opt-in is per kernel and sticks: once per process and instantiation
     if (fast) {
-        NSGP_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(rh_skinny_kernel<MB, B_ROWS, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+        if (!armed[1]) {
+            NSGP_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(rh_skinny_kernel<MB, B_ROWS, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+            armed[1] = true;
+        }
         hipLaunchKernelGGL((rh_skinny_kernel<MB, B_ROWS, true>), dim3(p.grid), dim3(256), smem, stream, g);
     } else {
-        NSGP_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(rh_skinny_kernel<MB, B_ROWS, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+        if (!armed[0]) {
+            NSGP_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(rh_skinny_kernel<MB, B_ROWS, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+            armed[0] = true;
+        }
         hipLaunchKernelGGL((rh_skinny_kernel<MB, B_ROWS, false>), dim3(p.grid), dim3(256), smem, stream, g);
     }
     NSGP_LAUNCH_CHECK();
@@ -502,9 +579,13 @@ extern "C" int repre_replay_head_forward(const float* bank, int n_rows, int in_f
     if ((rc = rh_launch_reduce(slabs, p, n_rows, hidden, b1, h1, stream))) return rc;
     if ((rc = rh_launch_skinny<true>(h1, hidden, w2, hidden, slabs, n_rows, hidden, hidden, p, stream))) return rc;
     if ((rc = rh_launch_reduce(slabs, p, n_rows, hidden, b2, h2, stream))) return rc;
-    hipLaunchKernelGGL(rh_scores_kernel, dim3((n_rows + 3) / 4), dim3(256), 0, stream, h2, n_rows, hidden, wc, bc, n_cols, scores);
+    float* rowloss = reinterpret_cast<float*>(static_cast<char*>(workspace) + W.rowloss);
+    hipLaunchKernelGGL(rh_scores_kernel, dim3((n_rows + RS_ROWS - 1) / RS_ROWS), dim3(256), 0, stream, h2, n_rows, hidden, wc, bc, n_cols,
+                       reinterpret_cast<const long long*>(labels), scores, rowloss);
     NSGP_LAUNCH_CHECK();
-    return repre_replay_ce_forward(scores, labels, n_rows, n_cols, loss_out, stream_);
+    hipLaunchKernelGGL(rh_mean_kernel, dim3(1), dim3(256), 0, stream, rowloss, n_rows, loss_out);
+    NSGP_LAUNCH_CHECK();
+    return NSGP_OK;
 }
 
 extern "C" int repre_replay_head_backward(const float* bank, int n_rows, int in_features, const float* w2, const float* wc, int hidden,
@@ -522,18 +603,21 @@ extern "C" int repre_replay_head_backward(const float* bank, int n_rows, int in_
     char* ws = static_cast<char*>(workspace);
     float* slabs = reinterpret_cast<float*>(ws + W.slabs);
     float* dS = reinterpret_cast<float*>(ws + W.dS);
-    float* dST = reinterpret_cast<float*>(ws + W.dST);
     float* dZ2 = reinterpret_cast<float*>(ws + W.dZ2);
     float* dZ2T = reinterpret_cast<float*>(ws + W.dZ2T);
     float* dZ1T = reinterpret_cast<float*>(ws + W.dZ1T);
     const int M = n_rows, Mp = (M + 31) / 32 * 32;
     if ((rc = repre_replay_ce_backward(scores, labels, M, n_cols, grad_out, dS, stream_))) return rc;
-    const int nblocks = (hidden + 31) / 32;
-    const size_t dz_lds = ((size_t)32 * (Mp + 1) + 8 * 32 + (size_t)n_cols * 32) * 4;
-    NSGP_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(rh_dz_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)dz_lds));
-    NSGP_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(rh_dz_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)dz_lds));
-    {   // dZ2 = (dS Wc) * (H2 > 0), its transposed copy, db2; dS^T and dbc
-        RhDz a{nullptr, 0, 0, dS, wc, n_cols, h2, M, hidden, Mp, dZ2, dZ2T, gb2, dST, gbc};
+    const int nblocks = (hidden + DZ_COLS - 1) / DZ_COLS;
+    const size_t dz_lds = ((size_t)DZ_COLS * (Mp + 1) + 16 * DZ_COLS + (size_t)n_cols * DZ_COLS + (size_t)DZ_RC * n_cols + DZ_RC * DZ_COLS) * 4;
+    static size_t dz_armed = 0;                  // the LDS opt-in sticks: raise it only when a larger tile comes along
+    if (dz_lds > dz_armed) {
+        NSGP_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(rh_dz_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)dz_lds));
+        NSGP_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(rh_dz_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)dz_lds));
+        dz_armed = dz_lds;
+    }
+    {   // dZ2 = (dS Wc) * (H2 > 0), its transposed copy, db2; the class heads' dWc = dS^T H2 and dbc
+        RhDz a{nullptr, 0, 0, dS, wc, n_cols, h2, M, hidden, Mp, dZ2, dZ2T, gb2, gwc, gbc};
         hipLaunchKernelGGL(rh_dz_kernel<1>, dim3(nblocks + 1), dim3(256), dz_lds, stream, a);
         NSGP_LAUNCH_CHECK();
     }
@@ -544,16 +628,19 @@ extern "C" int repre_replay_head_backward(const float* bank, int n_rows, int in_
         hipLaunchKernelGGL(rh_dz_kernel<0>, dim3(nblocks), dim3(256), dz_lds, stream, a);
         NSGP_LAUNCH_CHECK();
     }
-    // weight gradients: dW1 = dZ1^T X, dW2 = dZ2^T H1 (one grouped launch when both take the whole-tile path), dWc = dS^T H2
+    // weight gradients of the two shared FCs: dW1 = dZ1^T X, dW2 = dZ2^T H1 (one grouped launch when both take the whole-tile path)
     auto job = [&](const float* AT, const float* X, long ldx, float* out, int No, int Ni) {
         RhTnJob j{AT, X, out, ldx, (long)Ni, No, Ni, M, Mp, (Ni + BN - 1) / BN, 0};
         return j;
     };
     auto fast = [&](const RhTnJob& j) { return j.No % BM == 0 && j.Ni % BN == 0 && aligned16(j.AT) && aligned16(j.X) && aligned16(j.out) && j.ldx % 4 == 0; };
-    RhTnJob jobs[3] = {job(dZ1T, bank, in_features, gw1, hidden, in_features), job(dZ2T, h1, hidden, gw2, hidden, hidden),
-                       job(dST, h2, hidden, gwc, n_cols, hidden)};
-    NSGP_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(rh_tn_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, SMEM_BYTES));
-    NSGP_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(rh_tn_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, SMEM_BYTES));
+    RhTnJob jobs[2] = {job(dZ1T, bank, in_features, gw1, hidden, in_features), job(dZ2T, h1, hidden, gw2, hidden, hidden)};
+    static bool tn_armed = false;
+    if (!tn_armed) {
+        NSGP_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(rh_tn_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, SMEM_BYTES));
+        NSGP_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(rh_tn_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, SMEM_BYTES));
+        tn_armed = true;
+    }
     for (int pass = 0; pass < 2; ++pass) {
         RhTnArgs args{};
         int tiles = 0;
