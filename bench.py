@@ -415,7 +415,7 @@ def _pmc_file():
 
 
 def roofline_block(split, flops, abytes_kernel, gemm_ms, update_ms, n_prof, numel, ntiles, nproj, detail=None, lowrank=None,
-                   proj_numel=0, proj_bytes=0):
+                   proj_numel=0, proj_bytes=0, shape=None):
     """`roofline` of the NSGP step's dominant kernel, from HIP events the library records around each launch of the timed steps.
 
     DEFAULT path (every projected layer on the low-rank form; `lowrank` = the plan's low-rank stats, `detail` = per-launch ms):
@@ -443,15 +443,20 @@ def roofline_block(split, flops, abytes_kernel, gemm_ms, update_ms, n_prof, nume
     if lowrank and lowrank[0] == nproj and detail:
         plain_ms, fused_ms, dense_ms, reduce_ms, apply_ms = detail
         plain_numel = numel - proj_numel
-        out = hbm("nsgp_update_lr_kernel<SGD> (the projected layers' elementwise update fused with T = u U on the exact fp32 MFMA)",
-                  fused_ms, 20 * proj_numel, "g r+w (the reference's in-place grad.add_(wd, p), mirrored), momentum buffer r+w, p r = 20 B per element "
-                                             "of the 50 projected layers (26.6 M elements)")
+        merged = bool(shape) and shape[2] > 0 and shape[0] == 0      # the un-projected tensors' chunks ride in the fused launch's grid
+        fused_bytes = 20 * proj_numel + (24 * plain_numel if merged else 0)
+        out = hbm("nsgp_update_lr_kernel<SGD> (the projected layers' elementwise update fused with T = u U on the exact fp32 MFMA"
+                  + ("; the un-projected tensors' update rides at the end of its grid)" if merged else ")"),
+                  fused_ms, fused_bytes, "g r+w (the reference's in-place grad.add_(wd, p), mirrored), momentum buffer r+w, p r = 20 B per element "
+                                         "of the 50 projected layers (26.6 M elements)" + (" + g r+w, buf r+w, p r+w = 24 B per element of the un-projected "
+                                                                                          "tensors (14.6 M elements)" if merged else ""))
         out.update({"profiled_steps": n_prof, "layers": nproj, "traffic": tr.get("nsgp_update_lr_kernel_hbm_bytes_per_launch"),
                     "traffic_source": tr.get("source"),
                     "mfma_flops": lowrank[1] / 2, "mfma_frac_of_fp32_matrix_peak": lowrank[1] / 2 / (fused_ms * 1e-3) / 1e12 / PEAK_FP32_MATRIX_TFLOPS,
-                    "nsgp_step_launches": "nsgp_update_kernel -> nsgp_update_lr_kernel -> nsgp_lr_reduce_kernel -> nsgp_lr_apply_kernel",
-                    "elementwise": hbm("nsgp_update_kernel<SGD> (multi-tensor update of the un-projected tensors)", plain_ms, 24 * plain_numel,
-                                       "g r+w, buf r+w, p r+w = 24 B per element of the un-projected tensors (14.6 M elements)"),
+                    "nsgp_step_launches": ("" if merged else "nsgp_update_kernel -> ") + "nsgp_update_lr_kernel -> nsgp_lr_reduce_kernel -> nsgp_lr_apply_kernel",
+                    "launch_shape_workgroups": dict(zip(("update", "fused_lowrank_units", "fused_plain_chunks", "reduce", "apply"), shape)) if shape else None,
+                    "elementwise": None if merged else hbm("nsgp_update_kernel<SGD> (multi-tensor update of the un-projected tensors)", plain_ms, 24 * plain_numel,
+                                                           "g r+w, buf r+w, p r+w = 24 B per element of the un-projected tensors (14.6 M elements)"),
                     "lowrank_reduce_ms": reduce_ms,
                     "lowrank_apply": hbm("nsgp_lr_apply_kernel<SGD> (p += c (u - T U^T), exact fp32 MFMA, K = r)", apply_ms, 12 * proj_numel,
                                          "reads the update, reads and writes p = 12 B per projected element"),
@@ -603,7 +608,7 @@ def end_to_end_training(N, dev, world, local_rank, basis_cache, steps, warmup, a
            "nsgp_kernels_ms": update_ms + gemm_ms, "projected_layers": n_proj,
            "_roofline": dict(split=split, flops=flops, abytes_kernel=proj_bytes + 3 * 4 * proj_numel, gemm_ms=gemm_ms, update_ms=update_ms,
                              n_prof=n_prof, numel=all_numel, ntiles=ntiles, nproj=nproj, detail=detail, lowrank=lowrank,
-                             proj_numel=proj_numel, proj_bytes=proj_bytes),
+                             proj_numel=proj_numel, proj_bytes=proj_bytes, shape=opt.launch_shape()),
            "nsgp_launch_ms": dict(zip(("update", "update_lr_fused_t", "dense_gemm", "lowrank_reduce", "lowrank_apply"), detail)),
            "layers_on_low_rank_form": lowrank[0], "prototype_bank_rows": K, "task_split": split,
            "host_cores_per_rank": host_cores(),
@@ -698,8 +703,9 @@ def hot_path_only(N, dev, args, cache):
         "default": True, "ms_per_step": ms, "nsgp_step_ms": u_ms + g_ms, "update_kernel_ms": plain_ms, "update_lr_fused_t_kernel_ms": fused_ms,
         "lowrank_reduce_ms": t_ms, "lowrank_apply_ms": a_ms, "projection_launches_ms": g_ms, "layers": n_lr, "removed_directions_per_width": {str(D): int(v[1]) for D, v in sorted(cache.items())},
         "lowrank_flops": lr_flops, "dense_form_flops": flops, "dense_equivalent_tflops": flops / (g_ms * 1e-3) / 1e12,
-        "update_hbm_gbs": 24 * (flat_numel_real - proj_numel) / (plain_ms * 1e-3) / 1e9 if plain_ms else None,
-        "update_lr_fused_t_hbm_gbs": 20 * proj_numel / (fused_ms * 1e-3) / 1e9 if fused_ms else None,
+        "launch_shape_workgroups": dict(zip(("update", "fused_lowrank_units", "fused_plain_chunks", "reduce", "apply"), opt.launch_shape())),
+        "update_hbm_gbs": (24 * (flat_numel_real - proj_numel) / (plain_ms * 1e-3) / 1e9 if plain_ms else None) if opt.launch_shape()[0] else None,
+        "update_lr_fused_t_hbm_gbs": (20 * proj_numel + (24 * (flat_numel_real - proj_numel) if opt.launch_shape()[2] else 0)) / (fused_ms * 1e-3) / 1e9 if fused_ms else None,
         "bytes_note": "update: g r+w, buf r+w, p r+w = 24 B/element; fused update + T: g r+w, buf r+w, p r = 20 B/element; apply: u r, p r+w = 12 B/element",
         "lowrank_apply_hbm_gbs": 12 * proj_numel / (a_ms * 1e-3) / 1e9 if a_ms else None,
         "workgroups": {"update_lr_fused_t": lt1, "lowrank_apply": lt2},

@@ -164,6 +164,10 @@ int nsgp_plan_profile_end(nsgp_plan_t* plan, int* n_steps, float* update_ms_avg,
  * ms5[0] the multi-tensor elementwise launch, [1] the fused update + T = u U launch of the low-rank layers, [2] the dense GEMM
  * launch(es), [3] the slab reduce of the low-rank T, [4] the low-rank apply launch.  (_end's update_ms = [0] + [1], gemm_ms = the rest.) */
 int nsgp_plan_profile_detail(const nsgp_plan_t* plan, float* ms5);
+/* Launch shape of a step (ABI 8), workgroups: [0] the multi-tensor update launch (0 = that launch is not made), [1] the low-rank
+ * units of the fused update + T launch, [2] the chunks of the UN-PROJECTED tensors that ride at the end of that launch's grid (with
+ * low-rank layers in the plan the step has no separate launch for them), [3] the slab reduce, [4] the apply launch. */
+int nsgp_plan_launch_shape(const nsgp_plan_t* plan, int* shape5);
 
 /* Two-term fp16 split of diag(c) * proj^T with c[n] the power of two that brings the largest |entry| of projector column n
  * into [2^13, 2^14) (fp16 overflows at 65504).  `out` (16-byte aligned, nsgp_split_projector_f16_bytes(D) bytes, D % 64 == 0):

@@ -41,6 +41,7 @@ SIGNATURES = {
     "nsgp_plan_destroy": (C.c_int, [C.c_void_p]),
     "nsgp_plan_step": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(Hyper), C.c_int, C.c_void_p]),
     "nsgp_plan_stats": (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    "nsgp_plan_launch_shape": (C.c_int, [C.c_void_p, C.POINTER(C.c_int)]),
     "nsgp_plan_profile_detail": (C.c_int, [C.c_void_p, C.POINTER(C.c_float)]),
     "nsgp_plan_lowrank_stats": (C.c_int, [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_double), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "nsgp_plan_profile_begin": (C.c_int, [C.c_void_p, C.c_int]),

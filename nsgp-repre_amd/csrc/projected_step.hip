@@ -152,17 +152,15 @@ struct RowWalk {
     }
 };
 
-template <int OPT>
-__global__ __launch_bounds__(256) void nsgp_update_kernel(const ChunkDev* __restrict__ chunks,
-                                                          const TensorDev* __restrict__ tensors,
-                                                          const DynBlock* __restrict__ dyn) {
-    __shared__ unsigned s_rowmax[8];
-    __shared__ float s_rowscale[8];
-    const ChunkDev c = chunks[blockIdx.x];
+// One chunk of the multi-tensor update.  BANDS = false compiles the band path (row scales + split copy of the fp16 dense path) out:
+// that form is what the fused low-rank launch appends to its grid for the un-projected tensors.
+template <int OPT, bool BANDS>
+__device__ __forceinline__ void update_chunk(const ChunkDev c, const TensorDev* __restrict__ tensors, const DynBlock* __restrict__ dyn,
+                                             unsigned* s_rowmax, float* s_rowscale) {
     const TensorDev T = tensors[c.tensor];
     const nsgp_hyper_t h = dyn->hyper[T.hyper];
     float* __restrict__ gp = dyn->grads[c.tensor];
-    const bool band = c.band != 0;                       // uniform per workgroup
+    const bool band = BANDS && c.band != 0;              // uniform per workgroup
     const long span = band ? 8L * T.cols : (long)CHUNK;
     const long end = (c.start + span < T.numel) ? c.start + span : T.numel;
     const bool proj = T.projected != 0;
@@ -289,6 +287,15 @@ __global__ __launch_bounds__(256) void nsgp_update_kernel(const ChunkDev* __rest
         }
         v2_store_pieces(T.a_split, row0 + r, o, T.cols, lo, hi, s_rowscale[r]);
     }
+}
+
+template <int OPT>
+__global__ __launch_bounds__(256) void nsgp_update_kernel(const ChunkDev* __restrict__ chunks,
+                                                          const TensorDev* __restrict__ tensors,
+                                                          const DynBlock* __restrict__ dyn) {
+    __shared__ unsigned s_rowmax[8];
+    __shared__ float s_rowscale[8];
+    update_chunk<OPT, true>(chunks[blockIdx.x], tensors, dyn, s_rowmax, s_rowscale);
 }
 
 // ---- launch 2: grouped projection GEMM ---------------------------------------
@@ -483,8 +490,16 @@ __device__ __forceinline__ f32x4 lds_get4(const float* tile, int off) { return *
 // class, the U loads of blocks 1.. on the dependent chain: 78 us for each of the two wide classes of R-50-FPN.)
 template <int OPT>
 __global__ __launch_bounds__(256) void nsgp_update_lr_kernel(const TileDev* __restrict__ units, const LayerDev* __restrict__ layers,
-                                                             const TensorDev* __restrict__ tensors, const DynBlock* __restrict__ dyn) {
+                                                             const TensorDev* __restrict__ tensors, const DynBlock* __restrict__ dyn,
+                                                             int n_units, const ChunkDev* __restrict__ plain_chunks) {
     __shared__ __attribute__((aligned(16))) float lds[8 * LR_TILE];   // 2 buffers x 4 tiles; afterwards the waves' partial T blocks (1024 floats each)
+    // The grid's tail: the un-projected tensors' chunks (nsgp_update_kernel's work).  They are independent of the low-rank units, so
+    // they ride in this launch -- one launch boundary less (a boundary costs 10-17 us here: tail + ramp, profiles/r03/lr_groups_study.log),
+    // and 4,096-element chunks dispatched last fill the tail the 32-row units leave.
+    if ((int)blockIdx.x >= n_units) {
+        update_chunk<OPT, false>(plain_chunks[blockIdx.x - n_units], tensors, dyn, nullptr, nullptr);
+        return;
+    }
     const TileDev t = units[blockIdx.x];           // m0 = first row, pad = K range index
     const LayerDev L = layers[t.layer];
     const TensorDev T = tensors[L.tensor];
@@ -735,6 +750,8 @@ struct nsgp_plan {
     TileDev* d_tiles = nullptr;  // dense fast tiles | dense generic tiles | low-rank phase-1 | phase-2
     int n_tiles_lr1 = 0, n_tiles_lr2 = 0, n_lowrank = 0;    // low-rank: workgroups of the fused update + T launches and of the apply launch
     int n_chunks_lr = 0;
+    int n_chunks_plain = 0;       // chunks of the un-projected tensors appended to the fused low-rank launch (0 without low-rank layers)
+    ChunkDev* d_chunks_plain = nullptr;
     // cache blocking of the low-rank launches: the layers are cut into groups whose (update, p) working set fits the 256 MB
     // Infinity Cache, and fused -> reduce -> apply run group by group, so that the apply launch's re-read of the update and of p
     // (8 of its 12 bytes per element) is served by the memory-side cache instead of HBM.  Offsets / counts into d_tiles, d_chunks_lr.
@@ -811,7 +828,7 @@ extern "C" int nsgp_plan_create(nsgp_plan_t** out, const nsgp_tensor_t* tensors,
 
     std::vector<TensorDev> td(n);
     std::vector<LayerDev> ld;
-    std::vector<ChunkDev> cd;
+    std::vector<ChunkDev> cd, cd_plain;       // chunks of the projected tensors on a dense path | of the un-projected tensors
     std::vector<char> layer_fast;
     bool all_split = true;     // every fast dense layer carries a split copy of its projector, all of the same kind
     int split_kind = 0;
@@ -875,7 +892,13 @@ extern "C" int nsgp_plan_create(nsgp_plan_t** out, const nsgp_tensor_t* tensors,
         td[i] = d;
         if (t.proj && tensor_lowrank(t)) continue;                                                           // updated by the fused update + T launch
         if (d.a_split) for (long s = 0; s < t.numel; s += 8L * t.cols) cd.push_back(ChunkDev{i, 1, s});   // 8-row bands
-        else for (long s = 0; s < t.numel; s += CHUNK) cd.push_back(ChunkDev{i, 0, s});
+        else for (long s = 0; s < t.numel; s += CHUNK) (t.proj ? cd : cd_plain).push_back(ChunkDev{i, 0, s});
+    }
+    // with low-rank layers in the plan the un-projected tensors' chunks ride at the end of the fused launch's grid; otherwise they
+    // belong to the multi-tensor launch as before
+    if (n_lowrank == 0) {
+        cd.insert(cd.end(), cd_plain.begin(), cd_plain.end());
+        cd_plain.clear();
     }
     // longest workgroups first (a band of a 4608-wide layer is 36,864 elements, a linear chunk 16,384)
     std::stable_sort(cd.begin(), cd.end(), [&](const ChunkDev& a, const ChunkDev& b) {
@@ -953,6 +976,7 @@ extern "C" int nsgp_plan_create(nsgp_plan_t** out, const nsgp_tensor_t* tensors,
     P->n_tensors = n;
     P->n_layers = (int)ld.size();
     P->n_chunks = (int)cd.size();
+    P->n_chunks_plain = (int)cd_plain.size();
     P->n_tiles_fast = (int)fast_tiles.size();
     P->n_tiles_v2 = (int)v2_tiles.size();
     P->split_kind = (all_split && !(fast_tiles.empty() && v2_tiles.empty())) ? split_kind : 0;
@@ -1073,6 +1097,10 @@ extern "C" int nsgp_plan_create(nsgp_plan_t** out, const nsgp_tensor_t* tensors,
         PLAN_HIP(hipMalloc(&P->d_chunks, sizeof(ChunkDev) * cd.size()));
         PLAN_HIP(hipMemcpy(P->d_chunks, cd.data(), sizeof(ChunkDev) * cd.size(), hipMemcpyHostToDevice));
     }
+    if (!cd_plain.empty()) {
+        PLAN_HIP(hipMalloc(&P->d_chunks_plain, sizeof(ChunkDev) * cd_plain.size()));
+        PLAN_HIP(hipMemcpy(P->d_chunks_plain, cd_plain.data(), sizeof(ChunkDev) * cd_plain.size(), hipMemcpyHostToDevice));
+    }
     if (!lr_chunks.empty()) {
         PLAN_HIP(hipMalloc(&P->d_chunks_lr, sizeof(ChunkDev) * lr_chunks.size()));
         PLAN_HIP(hipMemcpy(P->d_chunks_lr, lr_chunks.data(), sizeof(ChunkDev) * lr_chunks.size(), hipMemcpyHostToDevice));
@@ -1126,6 +1154,7 @@ extern "C" int nsgp_plan_destroy(nsgp_plan_t* P) {
     if (P->d_tiles) keep(hipFree(P->d_tiles), "hipFree(tiles)");
     if (P->d_chunks) keep(hipFree(P->d_chunks), "hipFree(chunks)");
     if (P->d_chunks_lr) keep(hipFree(P->d_chunks_lr), "hipFree(chunks_lr)");
+    if (P->d_chunks_plain) keep(hipFree(P->d_chunks_plain), "hipFree(chunks_plain)");
     delete P;
     if (first != hipSuccess) return fail(NSGP_ERR_HIP, "nsgp_plan_destroy: %s failed: %s", what, hipGetErrorString(first));
     return NSGP_OK;
@@ -1150,6 +1179,16 @@ extern "C" int nsgp_plan_lowrank_stats(const nsgp_plan_t* P, int* n_lowrank, dou
 }
 
 extern "C" int nsgp_plan_uses_split_mfma(const nsgp_plan_t* P) { return P ? P->split_kind : 0; }
+
+extern "C" int nsgp_plan_launch_shape(const nsgp_plan_t* P, int* shape5) {
+    if (!P || !shape5) return fail(NSGP_ERR_INVALID, "nsgp_plan_launch_shape: null argument");
+    shape5[0] = P->n_chunks;            // workgroups of the multi-tensor update launch (0 = no such launch)
+    shape5[1] = P->n_tiles_lr1;         // low-rank (32-row block, K range) units of the fused update + T launch
+    shape5[2] = P->n_chunks_plain;      // chunks of the un-projected tensors appended to that launch
+    shape5[3] = P->n_chunks_lr;         // workgroups of the slab reduce
+    shape5[4] = P->n_tiles_lr2;         // workgroups of the apply launch
+    return NSGP_OK;
+}
 
 extern "C" int nsgp_plan_tile_counts(const nsgp_plan_t* P, int* fast_128, int* generic_128, int* split_f16_256) {
     if (!P) return fail(NSGP_ERR_INVALID, "nsgp_plan_tile_counts: null plan");
@@ -1233,10 +1272,13 @@ extern "C" int nsgp_plan_step(nsgp_plan_t* P, float* const* grads, const nsgp_hy
     const TileDev* t1 = P->d_tiles + P->n_tiles_fast + P->n_tiles_generic;
     const TileDev* t2 = t1 + P->n_tiles_lr1;
     for (const nsgp_plan::LrGroup& g : P->lr_groups) {
+        const int extra = (&g == &P->lr_groups.front()) ? P->n_chunks_plain : 0;      // the un-projected tensors ride in the first group's launch
         if (P->optimizer == NSGP_OPT_SGD)
-            hipLaunchKernelGGL(nsgp_update_lr_kernel<NSGP_OPT_SGD>, dim3(g.lr1_n), dim3(256), 0, stream, t1 + g.lr1_off, P->d_layers, P->d_tensors, d);
+            hipLaunchKernelGGL(nsgp_update_lr_kernel<NSGP_OPT_SGD>, dim3(g.lr1_n + extra), dim3(256), 0, stream, t1 + g.lr1_off, P->d_layers, P->d_tensors, d,
+                               g.lr1_n, P->d_chunks_plain);
         else
-            hipLaunchKernelGGL(nsgp_update_lr_kernel<NSGP_OPT_ADAM>, dim3(g.lr1_n), dim3(256), 0, stream, t1 + g.lr1_off, P->d_layers, P->d_tensors, d);
+            hipLaunchKernelGGL(nsgp_update_lr_kernel<NSGP_OPT_ADAM>, dim3(g.lr1_n + extra), dim3(256), 0, stream, t1 + g.lr1_off, P->d_layers, P->d_tensors, d,
+                               g.lr1_n, P->d_chunks_plain);
         NSGP_LAUNCH_CHECK();
         if (prof) NSGP_HIP(hipEventRecord(pe[ei++], stream));
         if (g.chunk_n > 0) {

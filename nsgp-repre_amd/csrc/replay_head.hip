@@ -209,53 +209,58 @@ __global__ __launch_bounds__(256) void rh_reduce_kernel(const float* __restrict_
     }
 }
 
-// scores[m][c] = bc[c] + sum_k H[m][k] Wc[c][k] for 8 rows per workgroup (thread = (row, class), H and Wc staged through LDS in
-// 256-wide k chunks, Wc rows padded to 257 floats: conflict-free), then the rows' double-softmax CE terms
-// rowloss[m] = logsumexp(softmax(s_m)) - softmax(s_m)[y_m]  (head:499) from the scores still in LDS, one wave per two rows.
-constexpr int RS_ROWS = 8, RS_KC = 256, RS_WLD = RS_KC + 1;
+// scores[m][c] = bc[c] + sum_k H[m][k] Wc[c][k]: ONE ROW per workgroup (K = 150 rows -> 150 workgroups), thread = (class, k slice):
+// 8 consecutive lanes read 128 contiguous bytes of one class row, 32 classes per pass, the 8 slices of a class are summed with
+// three shuffles; the row of H sits in LDS.  Then the row's double-softmax CE term rowloss[m] = logsumexp(softmax(s_m)) -
+// softmax(s_m)[y_m] (head:499) from the scores still in LDS.
+constexpr int RS_MAX_HIDDEN = 4096;
 __global__ __launch_bounds__(256) void rh_scores_kernel(const float* __restrict__ H, int M, int hidden, const float* __restrict__ Wc,
                                                         const float* __restrict__ bc, int C, const long long* __restrict__ labels,
                                                         float* __restrict__ scores, float* __restrict__ rowloss) {
-    __shared__ float Hs[RS_ROWS * RS_KC];
-    __shared__ float Ws[32 * RS_WLD];
-    __shared__ float sc[RS_ROWS * RH_MAX_COLS];
-    const int t = threadIdx.x, r = t >> 5, c = t & 31, m0 = blockIdx.x * RS_ROWS;
+    __shared__ __attribute__((aligned(16))) float hs[RS_MAX_HIDDEN];
+    __shared__ float sc[RH_MAX_COLS];
+    const int m = blockIdx.x, t = threadIdx.x, ks = t & 7, cl = t >> 3;
+    const bool staged = hidden <= RS_MAX_HIDDEN;
+    if (staged) {
+        for (int k = t; k < hidden; k += 256) hs[k] = H[(long)m * hidden + k];
+        __syncthreads();
+    }
+    const bool vec = staged && (hidden & 3) == 0 && ((uintptr_t)Wc & 15u) == 0;
     for (int c0 = 0; c0 < C; c0 += 32) {
+        const int c = c0 + cl;
         float acc = 0.0f;
-        for (int k0 = 0; k0 < hidden; k0 += RS_KC) {
-            __syncthreads();
-#pragma unroll
-            for (int i = 0; i < RS_ROWS; ++i) {
-                const int idx = t + 256 * i, rr = idx >> 8, kk = idx & 255;
-                Hs[idx] = (m0 + rr < M && k0 + kk < hidden) ? H[(long)(m0 + rr) * hidden + k0 + kk] : 0.0f;
+        if (c < C) {
+            const float* w = Wc + (long)c * hidden;
+            if (vec) {
+                for (int k = 4 * ks; k < hidden; k += 32) {
+                    const f32x4 wv = *(const gf32x4*)(w + k);
+                    const f32x4 hv = *reinterpret_cast<const f32x4*>(hs + k);
+                    acc += hv[0] * wv[0] + hv[1] * wv[1] + hv[2] * wv[2] + hv[3] * wv[3];
+                }
+            } else {
+                const float* hrow = staged ? hs : H + (long)m * hidden;
+                for (int k = ks; k < hidden; k += 8) acc += hrow[k] * w[k];
             }
-#pragma unroll 8
-            for (int i = 0; i < 32; ++i) {
-                const int idx = t + 256 * i, cc = idx >> 8, kk = idx & 255;
-                Ws[cc * RS_WLD + kk] = (c0 + cc < C && k0 + kk < hidden) ? Wc[(long)(c0 + cc) * hidden + k0 + kk] : 0.0f;
-            }
-            __syncthreads();
-#pragma unroll 8
-            for (int kk = 0; kk < RS_KC; ++kk) acc += Hs[r * RS_KC + kk] * Ws[c * RS_WLD + kk];
         }
-        if (c0 + c < C) {
-            const float v = acc + bc[c0 + c];
-            sc[r * RH_MAX_COLS + c0 + c] = v;
-            if (m0 + r < M) scores[(long)(m0 + r) * C + c0 + c] = v;
+        acc += __shfl_xor(acc, 1, 64);
+        acc += __shfl_xor(acc, 2, 64);
+        acc += __shfl_xor(acc, 4, 64);
+        if (ks == 0 && c < C) {
+            const float v = acc + bc[c];
+            sc[c] = v;
+            scores[(long)m * C + c] = v;
         }
     }
     __syncthreads();
-    const int lane = t & 63, wave = t >> 6;
-    for (int rr = 2 * wave; rr < 2 * wave + 2; ++rr) {
-        if (m0 + rr >= M) continue;                        // uniform per wave
+    if (t < 64) {
         float q[4];
-        const float lse = row_double_softmax(sc + rr * RH_MAX_COLS, C, lane, q);
-        const int y = (int)labels[m0 + rr];
+        const float lse = row_double_softmax(sc, C, t, q);
+        const int y = (int)labels[m];
         float qy = 0.0f;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) if (lane + 64 * e == y) qy = q[e];
+        for (int e = 0; e < 4; ++e) if (t + 64 * e == y) qy = q[e];
         qy = wave_sum(qy);
-        if (lane == 0) rowloss[m0 + rr] = lse - qy;
+        if (t == 0) rowloss[m] = lse - qy;
     }
 }
 
@@ -277,7 +282,7 @@ __global__ __launch_bounds__(256) void rh_mean_kernel(const float* __restrict__ 
 // or dS Wc (MODE 1).  Outputs: dZ (optional), dZT[n][m] (zero-padded to Mp columns: the A operand of the weight-gradient GEMM),
 // db[n] = sum_m dZ[m][n] (row groups summed in order).  MODE 1 also produces the class heads' gradients for its columns,
 // dWc[c][n] = sum_m dS[m][c] H[m][n] (rows in order, 64 at a time through LDS), and one extra workgroup writes dbc = column sums of dS.
-constexpr int DZ_COLS = 16, DZ_RC = 64, DZ_WACC = RH_MAX_COLS * DZ_COLS / 256;
+constexpr int DZ_COLS = 16, DZ_RC = 64, DZ_THREADS = 512, DZ_GROUPS = DZ_THREADS / DZ_COLS, DZ_WACC = RH_MAX_COLS * DZ_COLS / DZ_THREADS;
 struct RhDz {
     const float* slabs; int S; int Mpad;         // MODE 0
     const float* dS; const float* Wc; int C;     // MODE 1
@@ -290,12 +295,12 @@ struct RhDz {
 };
 
 template <int MODE>
-__global__ __launch_bounds__(256) void rh_dz_kernel(const RhDz a) {
+__global__ __launch_bounds__(DZ_THREADS) void rh_dz_kernel(const RhDz a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int t = threadIdx.x;
     const int nblocks = (a.N + DZ_COLS - 1) / DZ_COLS;
     if (MODE == 1 && (int)blockIdx.x == nblocks) {        // the extra workgroup: column sums of dS
-        for (int c = t; c < a.C; c += 256) {
+        for (int c = t; c < a.C; c += DZ_THREADS) {
             float s = 0.0f;
             for (int m = 0; m < a.M; ++m) s += a.dS[(long)m * a.C + c];
             a.dbc[c] = s;
@@ -305,12 +310,12 @@ __global__ __launch_bounds__(256) void rh_dz_kernel(const RhDz a) {
     const int c = t & (DZ_COLS - 1), grp = t / DZ_COLS, n0 = blockIdx.x * DZ_COLS, n = n0 + c;
     const int TLD = a.Mp + 1;
     float* tile = lds;                                   // [16][Mp + 1]
-    float* part = tile + DZ_COLS * TLD;                  // [16 groups][16]
-    float* wct = part + 16 * DZ_COLS;                    // MODE 1: [C][16]
+    float* part = tile + DZ_COLS * TLD;                  // [32 groups][16]
+    float* wct = part + DZ_GROUPS * DZ_COLS;                    // MODE 1: [C][16]
     float* dsc = wct + (MODE == 1 ? a.C * DZ_COLS : 0);  // MODE 1: [DZ_RC][C]
     float* hc = dsc + (MODE == 1 ? DZ_RC * a.C : 0);     // MODE 1: [DZ_RC][16]
     if (MODE == 1) {
-        for (int idx = t; idx < a.C * DZ_COLS; idx += 256) {
+        for (int idx = t; idx < a.C * DZ_COLS; idx += DZ_THREADS) {
             const int cc = idx / DZ_COLS, col = n0 + (idx & (DZ_COLS - 1));
             wct[idx] = (col < a.N) ? a.Wc[(long)cc * a.N + col] : 0.0f;
         }
@@ -324,22 +329,31 @@ __global__ __launch_bounds__(256) void rh_dz_kernel(const RhDz a) {
         const int rows = min(DZ_RC, a.M - m0);
         if (MODE == 1) {
             __syncthreads();
-            for (int idx = t; idx < rows * a.C; idx += 256) dsc[idx] = a.dS[(long)m0 * a.C + idx];
-            for (int idx = t; idx < rows * DZ_COLS; idx += 256) {
+            for (int idx = t; idx < rows * a.C; idx += DZ_THREADS) dsc[idx] = a.dS[(long)m0 * a.C + idx];
+            for (int idx = t; idx < rows * DZ_COLS; idx += DZ_THREADS) {
                 const int rr = idx / DZ_COLS, col = n0 + (idx & (DZ_COLS - 1));
                 hc[idx] = (col < a.N) ? a.H[(long)(m0 + rr) * a.N + col] : 0.0f;
             }
             __syncthreads();
         }
-        for (int rr = grp; rr < rows; rr += 256 / DZ_COLS) {
+        for (int rr = grp; rr < rows; rr += DZ_GROUPS) {
             const int m = m0 + rr;
             float v = 0.0f;
             if (n < a.N) {
                 float h;
                 if (MODE == 0) {
-                    v = a.slabs[(long)m * a.N + n];
-                    for (int s = 1; s < a.S; ++s) v += a.slabs[s * stride + (long)m * a.N + n];
+                    const float* sp = a.slabs + (long)m * a.N + n;
                     h = a.H[(long)m * a.N + n];
+                    v = sp[0];
+                    int s = 1;
+                    for (; s + 8 <= a.S; s += 8) {
+                        float u[8];
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) u[e] = sp[(s + e) * stride];
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) v += u[e];
+                    }
+                    for (; s < a.S; ++s) v += sp[s * stride];
                 } else {
                     for (int cc = 0; cc < a.C; ++cc) v += dsc[rr * a.C + cc] * wct[cc * DZ_COLS + c];
                     h = hc[rr * DZ_COLS + c];
@@ -353,7 +367,7 @@ __global__ __launch_bounds__(256) void rh_dz_kernel(const RhDz a) {
         if (MODE == 1) {
 #pragma unroll
             for (int j = 0; j < DZ_WACC; ++j) {
-                const int idx = t + 256 * j;
+                const int idx = t + DZ_THREADS * j;
                 if (idx < a.C * DZ_COLS) {
                     const int cc = idx / DZ_COLS, nn = idx & (DZ_COLS - 1);
                     float s = 0.0f;
@@ -367,17 +381,17 @@ __global__ __launch_bounds__(256) void rh_dz_kernel(const RhDz a) {
     __syncthreads();
     if (grp == 0 && n < a.N) {
         float s = part[c];
-        for (int k = 1; k < 256 / DZ_COLS; ++k) s += part[k * DZ_COLS + c];
+        for (int k = 1; k < DZ_GROUPS; ++k) s += part[k * DZ_COLS + c];
         a.db[n] = s;
     }
-    for (int idx = t; idx < DZ_COLS * a.Mp; idx += 256) {
+    for (int idx = t; idx < DZ_COLS * a.Mp; idx += DZ_THREADS) {
         const int cc = idx / a.Mp, m = idx - cc * a.Mp;
         if (n0 + cc < a.N) a.dZT[(long)(n0 + cc) * a.Mp + m] = (m < a.M) ? tile[cc * TLD + m] : 0.0f;
     }
     if (MODE == 1) {
 #pragma unroll
         for (int j = 0; j < DZ_WACC; ++j) {
-            const int idx = t + 256 * j;
+            const int idx = t + DZ_THREADS * j;
             if (idx < a.C * DZ_COLS) {
                 const int cc = idx / DZ_COLS, col = n0 + (idx & (DZ_COLS - 1));
                 if (col < a.N) a.dWc[(long)cc * a.N + col] = wacc[j];
@@ -580,7 +594,7 @@ extern "C" int repre_replay_head_forward(const float* bank, int n_rows, int in_f
     if ((rc = rh_launch_skinny<true>(h1, hidden, w2, hidden, slabs, n_rows, hidden, hidden, p, stream))) return rc;
     if ((rc = rh_launch_reduce(slabs, p, n_rows, hidden, b2, h2, stream))) return rc;
     float* rowloss = reinterpret_cast<float*>(static_cast<char*>(workspace) + W.rowloss);
-    hipLaunchKernelGGL(rh_scores_kernel, dim3((n_rows + RS_ROWS - 1) / RS_ROWS), dim3(256), 0, stream, h2, n_rows, hidden, wc, bc, n_cols,
+    hipLaunchKernelGGL(rh_scores_kernel, dim3(n_rows), dim3(256), 0, stream, h2, n_rows, hidden, wc, bc, n_cols,
                        reinterpret_cast<const long long*>(labels), scores, rowloss);
     NSGP_LAUNCH_CHECK();
     hipLaunchKernelGGL(rh_mean_kernel, dim3(1), dim3(256), 0, stream, rowloss, n_rows, loss_out);
@@ -609,7 +623,7 @@ extern "C" int repre_replay_head_backward(const float* bank, int n_rows, int in_
     const int M = n_rows, Mp = (M + 31) / 32 * 32;
     if ((rc = repre_replay_ce_backward(scores, labels, M, n_cols, grad_out, dS, stream_))) return rc;
     const int nblocks = (hidden + DZ_COLS - 1) / DZ_COLS;
-    const size_t dz_lds = ((size_t)DZ_COLS * (Mp + 1) + 16 * DZ_COLS + (size_t)n_cols * DZ_COLS + (size_t)DZ_RC * n_cols + DZ_RC * DZ_COLS) * 4;
+    const size_t dz_lds = ((size_t)DZ_COLS * (Mp + 1) + DZ_GROUPS * DZ_COLS + (size_t)n_cols * DZ_COLS + (size_t)DZ_RC * n_cols + DZ_RC * DZ_COLS) * 4;
     static size_t dz_armed = 0;                  // the LDS opt-in sticks: raise it only when a larger tile comes along
     if (dz_lds > dz_armed) {
         NSGP_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(rh_dz_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)dz_lds));
@@ -618,14 +632,14 @@ extern "C" int repre_replay_head_backward(const float* bank, int n_rows, int in_
     }
     {   // dZ2 = (dS Wc) * (H2 > 0), its transposed copy, db2; the class heads' dWc = dS^T H2 and dbc
         RhDz a{nullptr, 0, 0, dS, wc, n_cols, h2, M, hidden, Mp, dZ2, dZ2T, gb2, gwc, gbc};
-        hipLaunchKernelGGL(rh_dz_kernel<1>, dim3(nblocks + 1), dim3(256), dz_lds, stream, a);
+        hipLaunchKernelGGL(rh_dz_kernel<1>, dim3(nblocks + 1), dim3(DZ_THREADS), dz_lds, stream, a);
         NSGP_LAUNCH_CHECK();
     }
     RhPlan p;    // dH1 = dZ2 W2   (W2 is [hidden(k) x hidden(n)] row-major for this product)
     if ((rc = rh_launch_skinny<false>(dZ2, hidden, w2, hidden, slabs, M, hidden, hidden, p, stream))) return rc;
     {   // dZ1 = dH1 * (H1 > 0): only its transposed copy is needed (dX is not: the bank is a constant), db1
         RhDz a{slabs, p.S, p.Mpad, nullptr, nullptr, 0, h1, M, hidden, Mp, nullptr, dZ1T, gb1, nullptr, nullptr};
-        hipLaunchKernelGGL(rh_dz_kernel<0>, dim3(nblocks), dim3(256), dz_lds, stream, a);
+        hipLaunchKernelGGL(rh_dz_kernel<0>, dim3(nblocks), dim3(DZ_THREADS), dz_lds, stream, a);
         NSGP_LAUNCH_CHECK();
     }
     // weight gradients of the two shared FCs: dW1 = dZ1^T X, dW2 = dZ2^T H1 (one grouped launch when both take the whole-tile path)

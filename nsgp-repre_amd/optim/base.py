@@ -434,6 +434,17 @@ class NSCLOptimizerBase(Optimizer):
             tot = [tot[0] + n.value, tot[1] + f.value, tot[2] + a.value, tot[3] + b.value]
         return tuple(tot)
 
+    def launch_shape(self):
+        """Workgroups per launch of a step, summed over the current plans: (multi-tensor update launch, low-rank units of the fused
+        update + T launch, chunks of the un-projected tensors riding in that launch, slab reduce, apply launch)."""
+        lib = _lib.load_library()
+        tot = [0] * 5
+        for plan in self._plans:
+            sh = (C.c_int * 5)()
+            _lib.check(lib.nsgp_plan_launch_shape(plan["handle"], sh), "nsgp_plan_launch_shape")
+            tot = [a + b for a, b in zip(tot, sh)]
+        return tuple(tot)
+
     def profile_begin(self, max_steps=1024):
         """Record HIP events around both launches of the next ``max_steps`` steps (measurement)."""
         lib = _lib.load_library()
