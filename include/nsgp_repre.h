@@ -205,6 +205,27 @@ int nsgp_cov_accumulate_conv2d(const float* x, int batch, int cin, int h, int w,
                                int sh, int sw, int ph, int pw, float* cov, int accumulate,
                                void* workspace, size_t workspace_bytes, void* stream);
 /* Linear branch (runner:901-902): X = mean(x, 0, keepdim) with x [B x F] -> C (+)= X^T X (rank 1). */
+/* Grouped covariance pass: every eligible hooked convolution of ONE forward in five launches (mean / amax / operand split / one
+ * tile table over all layers, longest K first, no split-K and no reduce: each tile writes its block of C and the mirror).  Replaces
+ * the per-hook launches of compute_cov + update_cov, nsrunner_roi_replay.py:876-934, for a whole forward of cal_fea_in (:705-763).
+ * A plan is built once per model geometry; nsgp_cov_plan_routes says which layers the grouped launches take (1) and which stay on
+ * nsgp_cov_accumulate_conv2d (0: D = cin*kh*kw not a multiple of 64, or fewer than 32 output positions).  nsgp_cov_plan_run borrows
+ * x[i] ([batch x cin x h x w] fp32), cov[i] ([D x D] fp32) for the layers of route 1 (entries of route-0 layers are ignored) and
+ * assigns (accumulate[i] == 0) or adds; the covariances of one run must be distinct buffers.  workspace: >=
+ * nsgp_cov_plan_workspace_bytes(plan), 16-byte aligned (the materialised two-term fp16 operands of all layers: ~2.4 GB for R-50-FPN at
+ * 800 x 1344).  Deterministic: every element of C is produced by one tile in a fixed order. */
+typedef struct nsgp_cov_plan nsgp_cov_plan_t;
+typedef struct {
+    int32_t batch, cin, h, w, kh, kw, sh, sw, ph, pw;
+} nsgp_cov_geom_t;
+int nsgp_cov_plan_create(nsgp_cov_plan_t** out, const nsgp_cov_geom_t* layers, int n);
+int nsgp_cov_plan_destroy(nsgp_cov_plan_t* plan);
+size_t nsgp_cov_plan_workspace_bytes(const nsgp_cov_plan_t* plan);
+int nsgp_cov_plan_routes(const nsgp_cov_plan_t* plan, int* routes, int n);
+/* n_grouped layers, tiles of the SYRK launch, and sum over the grouped layers of L*D*(D+128) = the FLOPs of the upper triangles (blocks on the diagonal counted whole) */
+int nsgp_cov_plan_stats(const nsgp_cov_plan_t* plan, int* n_grouped, int* n_tiles, double* upper_flops);
+int nsgp_cov_plan_run(nsgp_cov_plan_t* plan, const float* const* x, float* const* cov, const int* accumulate, void* workspace,
+                      size_t workspace_bytes, void* stream);
 int nsgp_cov_accumulate_linear(const float* x, int batch, int features, float* cov, int accumulate,
                                void* stream);
 

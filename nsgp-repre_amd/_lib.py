@@ -29,6 +29,11 @@ class Hyper(C.Structure):
                 ("reserved", C.c_int32)]
 
 
+class CovGeom(C.Structure):
+    """nsgp_cov_geom_t"""
+    _fields_ = [(k, C.c_int32) for k in ("batch", "cin", "h", "w", "kh", "kw", "sh", "sw", "ph", "pw")]
+
+
 # every exported symbol of include/nsgp_repre.h: name -> (restype, argtypes)
 SIGNATURES = {
     "nsgp_abi_version": (C.c_int, []),
@@ -49,6 +54,12 @@ SIGNATURES = {
     "nsgp_project": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_int, C.c_void_p]),
     "nsgp_cov_workspace_bytes": (C.c_size_t, [C.c_int] * 9),
     "nsgp_cov_accumulate_conv2d": (C.c_int, [C.c_void_p] + [C.c_int] * 10 + [C.c_void_p, C.c_int, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "nsgp_cov_plan_create": (C.c_int, [C.POINTER(C.c_void_p), C.POINTER(CovGeom), C.c_int]),
+    "nsgp_cov_plan_destroy": (C.c_int, [C.c_void_p]),
+    "nsgp_cov_plan_workspace_bytes": (C.c_size_t, [C.c_void_p]),
+    "nsgp_cov_plan_routes": (C.c_int, [C.c_void_p, C.POINTER(C.c_int), C.c_int]),
+    "nsgp_cov_plan_stats": (C.c_int, [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_double)]),
+    "nsgp_cov_plan_run": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_int), C.c_void_p, C.c_size_t, C.c_void_p]),
     "nsgp_cov_accumulate_linear": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p]),
     "nsgp_projector_scratch_bytes": (C.c_size_t, [C.c_int]),
     "nsgp_build_projector": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),

@@ -16,6 +16,8 @@
 //   3. nsgp_cov_reduce_kernel      per tile: C (=|+=) sum of its segments' slabs in workgroup order
 //      (deterministic; no float atomics), mirrored into the lower triangle through LDS.
 #include <algorithm>
+#include <new>
+#include <vector>
 
 #include "common.hpp"
 #include "gemm_core.hpp"
@@ -679,6 +681,389 @@ extern "C" int nsgp_cov_accumulate_conv2d(const float* x, int batch, int cin, in
     hipLaunchKernelGGL(nsgp_cov_reduce_kernel, dim3((unsigned)p.tiles, bands), dim3(256), 0, stream, slabs, g.D, p.nk, p.G, p.P,
                        BM / bands, cov, accumulate, split ? amax : nullptr);
     NSGP_LAUNCH_CHECK();
+    return NSGP_OK;
+}
+
+namespace nsgp {
+
+// ---- grouped pass: every eligible hooked layer of ONE forward in five launches ------------------------------------------------
+// One hooked forward of R-50-FPN is 61 accumulations; issued layer by layer they are 4-5 launches each, most of them far too small
+// to fill 256 CUs, every wide layer needs split-K slabs + a reduce launch to fill the chip on its own, and each pays a memset +
+// amax launch for its fp16 scale (round 2: 7.4 ms of back-to-back GPU time, 5.6 ms over four streams).  Here the hooks only stash
+// their inputs; at the end of the forward ONE plan run does, for all layers with D % 64 == 0 together:
+//   nsgp_cov_group_mean_kernel   batch mean + zero border, for the layers that need it (B > 1 or padding);
+//   nsgp_cov_group_amax_kernel   largest |activation| per layer -> its power-of-two fp16 scale;
+//   nsgp_cov_group_split_kernel  X^T of every layer as the pre-tiled, pre-scaled two-term fp16 operand (gemm_f16x2_v2.hpp);
+//   nsgp_cov_group_syrk_kernel   ONE tile table over all layers, longest K first (in-order dispatch = LPT list scheduling on the
+//                                256 one-workgroup CUs).  With ~2,500 tiles from 60 layers in one launch the chip is full without
+//                                split-K: a tile contracts its whole L, and its epilogue unscales and writes (or accumulates into) C
+//                                directly -- upper-triangle blocks plus their mirrors, diagonal blocks symmetrised through LDS -- so
+//                                there are no slabs and no reduce launch.  Every element of C is written by exactly one tile in a
+//                                fixed k order: bitwise reproducible.
+// Layers the tile cannot take (D % 64 != 0: the 7x7 stem; Linear) stay on the single-layer entry points.
+struct CovGroupLayer {
+    ConvGeom g;
+    int cin, H, W, ph, pw, batch;
+    int Dp, Lp;
+    int needs_mean;          // 0: the input is its own batch mean (B == 1, no padding)
+    long xm_off, xt_off;     // byte offsets into the workspace
+    long n_img;              // elements of the (padded) mean image
+};
+struct CovGroupTile {
+    int layer, rb0, cb0, mb;
+};
+
+__device__ __forceinline__ int cov_group_find(const int* __restrict__ prefix, int n, int unit) {
+    int lo = 0;
+    while (lo + 1 < n && unit >= prefix[lo + 1]) ++lo;      // n <= ~120: a short uniform scan
+    return lo;
+}
+
+constexpr int CG_CHUNK = 256 * 16;       // elements per workgroup of the mean / amax launches
+
+// dyn: [x pointers n][cov pointers n][accumulate flags n]
+__device__ __forceinline__ const float* cg_x(const void* dyn, int i) { return reinterpret_cast<const float* const*>(dyn)[i]; }
+__device__ __forceinline__ float* cg_cov(const void* dyn, int n, int i) { return reinterpret_cast<float* const*>(dyn)[n + i]; }
+__device__ __forceinline__ int cg_acc(const void* dyn, int n, int i) { return reinterpret_cast<const int*>(reinterpret_cast<const float* const*>(dyn) + 2 * n)[i]; }
+
+__global__ __launch_bounds__(256) void nsgp_cov_group_mean_kernel(const CovGroupLayer* __restrict__ layers, const int* __restrict__ prefix, int n,
+                                                                  const void* __restrict__ dyn, char* __restrict__ ws) {
+    const int li = cov_group_find(prefix, n, blockIdx.x);
+    const CovGroupLayer L = layers[li];
+    const float* __restrict__ x = cg_x(dyn, li);
+    float* __restrict__ xm = reinterpret_cast<float*>(ws + L.xm_off);
+    const int Hp = L.H + 2 * L.ph, Wp = L.W + 2 * L.pw;
+    const long base = (long)(blockIdx.x - prefix[li]) * CG_CHUNK;
+    const long bs = (long)L.cin * L.H * L.W;
+    for (long idx = base + threadIdx.x; idx < min(base + CG_CHUNK, L.n_img); idx += 256) {
+        const int xx = (int)(idx % Wp), yy = (int)((idx / Wp) % Hp), c = (int)(idx / ((long)Wp * Hp));
+        float v = 0.0f;
+        if (yy >= L.ph && yy < L.ph + L.H && xx >= L.pw && xx < L.pw + L.W) {
+            const long off = ((long)c * L.H + (yy - L.ph)) * L.W + (xx - L.pw);
+            float s = x[off];
+            for (int b = 1; b < L.batch; ++b) s += x[off + b * bs];      // torch.mean(x, 0, True): sum over b, then / B
+            v = (L.batch > 1) ? s / (float)L.batch : s;
+        }
+        xm[idx] = v;
+    }
+}
+
+__device__ __forceinline__ const float* cg_image(const CovGroupLayer& L, const void* dyn, int li, const char* ws) {
+    return L.needs_mean ? reinterpret_cast<const float*>(ws + L.xm_off) : cg_x(dyn, li);
+}
+
+__global__ __launch_bounds__(256) void nsgp_cov_group_amax_kernel(const CovGroupLayer* __restrict__ layers, const int* __restrict__ prefix, int n,
+                                                                  const void* __restrict__ dyn, const char* __restrict__ ws, unsigned* __restrict__ amax) {
+    const int li = cov_group_find(prefix, n, blockIdx.x);
+    const CovGroupLayer L = layers[li];
+    const float* __restrict__ xm = cg_image(L, dyn, li, ws);
+    const long base = (long)(blockIdx.x - prefix[li]) * CG_CHUNK, end = min(base + CG_CHUNK, L.n_img);
+    float am = 0.0f;
+    if ((((uintptr_t)xm) & 15u) == 0 && end - base == CG_CHUNK) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const f32x4 q = *(const gf32x4*)(xm + base + 4 * (threadIdx.x + 256 * i));
+            am = fmaxf(fmaxf(am, fmaxf(fabsf(q[0]), fabsf(q[1]))), fmaxf(fabsf(q[2]), fabsf(q[3])));
+        }
+    } else {
+        for (long i = base + threadIdx.x; i < end; i += 256) am = fmaxf(am, fabsf(as_global(xm)[i]));
+    }
+    for (int off = 32; off > 0; off >>= 1) am = fmaxf(am, __shfl_xor(am, off, 64));
+    __shared__ float wmax[4];
+    if ((threadIdx.x & 63) == 0) wmax[threadIdx.x >> 6] = am;
+    __syncthreads();
+    if (threadIdx.x == 0) atomicMax(amax + li, __float_as_uint(fmaxf(fmaxf(wmax[0], wmax[1]), fmaxf(wmax[2], wmax[3]))));
+}
+
+// one wave = one (64-row block, l-octet) of one layer, as nsgp_cov_im2col_split_kernel
+__global__ __launch_bounds__(256) void nsgp_cov_group_split_kernel(const CovGroupLayer* __restrict__ layers, const int* __restrict__ prefix, int n,
+                                                                   const void* __restrict__ dyn, char* __restrict__ ws, const unsigned* __restrict__ amax) {
+    const int li = cov_group_find(prefix, n, blockIdx.x);
+    const CovGroupLayer L = layers[li];
+    const int u = blockIdx.x - prefix[li];
+    const int nob = (L.Lp / 8 + 3) / 4;                      // workgroups along l (4 octets each)
+    const int ob = u % nob, db = u / nob;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int o = ob * 4 + wave;
+    if (o * 8 >= L.Lp) return;
+    const float* __restrict__ xm = cg_image(L, dyn, li, ws);
+    const int d = db * 64 + lane;
+    const float scale = f2_scale_from_amax_bits(amax[li]);
+    f32x4 r[2];
+    r[0] = f32x4{0, 0, 0, 0};
+    r[1] = f32x4{0, 0, 0, 0};
+    if (d < L.g.D && o * 8 < L.g.L) {
+        const Patch8 pc = patch8(L.g, 1.0f / (float)L.g.Wo, o * 8, L.g.L);
+        stage8(xm, im2col_rowbase1(L.g, d), pc, r);
+    }
+    v2_store_pieces(ws + L.xt_off, d, o, L.Lp, r[0], r[1], scale);
+}
+
+constexpr int CG_TLD = 129;              // floats per row of the epilogue tile: transposed reads stay conflict-free
+static_assert(256 * CG_TLD * 4 <= V2_SMEM_BYTES, "the epilogue tile must fit the ring");
+
+__global__ __launch_bounds__(V2L_THREADS, 3) void nsgp_cov_group_syrk_kernel(const CovGroupTile* __restrict__ tiles, const CovGroupLayer* __restrict__ layers,
+                                                                            int n, const void* __restrict__ dyn, const char* __restrict__ ws,
+                                                                            const unsigned* __restrict__ amax) {
+    extern __shared__ __attribute__((aligned(16))) char smem_c[];
+    const CovGroupTile t = tiles[blockIdx.x];
+    const CovGroupLayer L = layers[t.layer];
+    const void* xt = ws + L.xt_off;
+    f32x16 acc[2][2];
+    zero_acc(acc);
+    if (t.mb == 4) gemm_tile_f16x2_v2l<4>(xt, t.rb0, xt, t.cb0, L.Lp, smem_c, acc);
+    else gemm_tile_f16x2_v2l<2>(xt, t.rb0, xt, t.cb0, L.Lp, smem_c, acc);
+    // every wave is back (the loaders too) and the ring is free: park the unscaled 256 (128) x 128 block in LDS
+    float* T = reinterpret_cast<float*>(smem_c);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const float sc = f2_scale_from_amax_bits(amax[t.layer]);
+    const float unscale = (1.0f / sc) * (1.0f / sc);
+    if (wave < 2 * t.mb) {
+        const int wm = wave >> 1, wn = wave & 1;
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    T[(wm * 64 + mi * 32 + acc_row(r, lane)) * CG_TLD + wn * 64 + ni * 32 + (lane & 31)] = acc[mi][ni][r] * unscale;
+    }
+    __syncthreads();
+    gfloat* cov = as_global(cg_cov(dyn, n, t.layer));
+    const bool accumulate = cg_acc(dyn, n, t.layer) != 0;
+    const int D = L.g.D;
+    for (int sb = 0; sb < t.mb / 2; ++sb) {                      // the 128 x 128 blocks of this tile
+        const int ti = t.rb0 / 2 + sb, tj = t.cb0 / 2;
+        if (ti > tj) continue;                                   // below the diagonal: the mirror of a block another tile owns
+        const int m0 = ti * 128, n0 = tj * 128;
+        const float* Tb = T + sb * 128 * CG_TLD;
+        if (ti == tj) {
+            // diagonal block: (i,j) and (j,i) hold the same products in a different order -- take the upper triangle for both
+            for (int idx = threadIdx.x; idx < 128 * 128; idx += V2L_THREADS) {
+                const int r = idx >> 7, c = idx & 127;
+                if (m0 + r < D && n0 + c < D) {
+                    const float v = (c >= r) ? Tb[r * CG_TLD + c] : Tb[c * CG_TLD + r];
+                    const long o = (long)(m0 + r) * D + n0 + c;
+                    cov[o] = accumulate ? (cov[o] + v) : v;
+                }
+            }
+        } else {
+            for (int idx = threadIdx.x; idx < 128 * 128; idx += V2L_THREADS) {
+                const int r = idx >> 7, c = idx & 127;
+                if (m0 + r < D && n0 + c < D) {
+                    const long o = (long)(m0 + r) * D + n0 + c;
+                    const float v = Tb[r * CG_TLD + c];
+                    cov[o] = accumulate ? (cov[o] + v) : v;
+                }
+            }
+            for (int idx = threadIdx.x; idx < 128 * 128; idx += V2L_THREADS) {      // mirror: r fastest
+                const int c = idx >> 7, r = idx & 127;
+                if (m0 + r < D && n0 + c < D) {
+                    const long o = (long)(n0 + c) * D + m0 + r;
+                    const float v = Tb[r * CG_TLD + c];
+                    cov[o] = accumulate ? (cov[o] + v) : v;
+                }
+            }
+        }
+    }
+}
+
+}  // namespace nsgp
+
+struct nsgp_cov_plan {
+    int n = 0;                       // layers handed to create
+    int n_group = 0;                 // of which on the grouped launches
+    std::vector<int> route;          // per layer: index into the grouped tables, or -1 (single-layer entry points)
+    size_t ws_bytes = 0, amax_off = 0;
+    int mean_units = 0, amax_units = 0, split_units = 0, n_tiles = 0;
+    nsgp::CovGroupLayer* d_layers = nullptr;
+    nsgp::CovGroupTile* d_tiles = nullptr;
+    int* d_prefix = nullptr;         // three prefix arrays of n_group + 1 ints: mean, amax, split
+    size_t dyn_bytes = 0;
+    char* h_dyn[4] = {nullptr, nullptr, nullptr, nullptr};
+    char* d_dyn[4] = {nullptr, nullptr, nullptr, nullptr};
+    hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+    bool ev_used[4] = {false, false, false, false};
+    int slot = 0;
+    double flops_upper = 0;          // sum over grouped layers of L * D * (D + 128): the upper-triangle work actually needed
+};
+
+namespace nsgp {
+static bool cov_group_eligible(const nsgp_cov_geom_t& q, int& D, int& L, int& Wo, int& Hp, int& Wp) {
+    if (q.cin <= 0 || q.h <= 0 || q.w <= 0 || q.kh <= 0 || q.kw <= 0 || q.sh <= 0 || q.sw <= 0 || q.ph < 0 || q.pw < 0 || q.batch <= 0) return false;
+    Hp = q.h + 2 * q.ph;
+    Wp = q.w + 2 * q.pw;
+    const int Ho = (Hp - q.kh) / q.sh + 1;
+    Wo = (Wp - q.kw) / q.sw + 1;
+    if (Ho <= 0 || Wo <= 0) return false;
+    D = q.cin * q.kh * q.kw;
+    L = Ho * Wo;
+    return D % 64 == 0 && L >= 32;
+}
+}  // namespace nsgp
+
+using namespace nsgp;
+
+extern "C" int nsgp_cov_plan_destroy(nsgp_cov_plan_t* P) {
+    if (!P) return NSGP_OK;
+    hipError_t first = hipSuccess;
+    auto keep = [&](hipError_t e) { if (e != hipSuccess && first == hipSuccess) first = e; };
+    for (int s = 0; s < 4; ++s)
+        if (P->ev[s] && P->ev_used[s]) keep(hipEventSynchronize(P->ev[s]));
+    for (int s = 0; s < 4; ++s) {
+        if (P->ev[s]) keep(hipEventDestroy(P->ev[s]));
+        if (P->h_dyn[s]) keep(hipHostFree(P->h_dyn[s]));
+        if (P->d_dyn[s]) keep(hipFree(P->d_dyn[s]));
+    }
+    if (P->d_layers) keep(hipFree(P->d_layers));
+    if (P->d_tiles) keep(hipFree(P->d_tiles));
+    if (P->d_prefix) keep(hipFree(P->d_prefix));
+    delete P;
+    if (first != hipSuccess) return fail(NSGP_ERR_HIP, "nsgp_cov_plan_destroy: %s", hipGetErrorString(first));
+    return NSGP_OK;
+}
+
+extern "C" int nsgp_cov_plan_create(nsgp_cov_plan_t** out, const nsgp_cov_geom_t* geoms, int n) {
+    if (!out || !geoms || n <= 0) return fail(NSGP_ERR_INVALID, "nsgp_cov_plan_create: null / empty layer list");
+    nsgp_cov_plan* P = new (std::nothrow) nsgp_cov_plan();
+    if (!P) return fail(NSGP_ERR_INVALID, "out of host memory");
+    P->n = n;
+    P->route.assign(n, -1);
+    std::vector<CovGroupLayer> ld;
+    std::vector<int> pm{0}, pa{0}, ps{0};
+    size_t off = 0;
+    for (int i = 0; i < n; ++i) {
+        const nsgp_cov_geom_t& q = geoms[i];
+        int D, L, Wo, Hp, Wp;
+        if (!cov_group_eligible(q, D, L, Wo, Hp, Wp)) continue;
+        CovGroupLayer c{};
+        c.g = ConvGeom{D, L, Wo, q.kh, q.kw, q.sh, q.sw, Hp, Wp};
+        c.cin = q.cin; c.H = q.h; c.W = q.w; c.ph = q.ph; c.pw = q.pw; c.batch = q.batch;
+        c.Dp = cov2_pad_d(D);
+        c.Lp = cov2_pad_l(L);
+        c.needs_mean = !(q.batch == 1 && q.ph == 0 && q.pw == 0);
+        c.n_img = (long)q.cin * Hp * Wp;
+        c.xm_off = -1;
+        if (c.needs_mean) { c.xm_off = (long)off; off += align256((size_t)c.n_img * 4); }
+        P->route[i] = (int)ld.size();
+        ld.push_back(c);
+    }
+    for (CovGroupLayer& c : ld) { c.xt_off = (long)off; off += align256(v2_operand_bytes(c.Dp, c.Lp)); }
+    P->amax_off = off;
+    off += align256(std::max<size_t>(1, ld.size()) * sizeof(unsigned));
+    P->ws_bytes = off;
+    P->n_group = (int)ld.size();
+    std::vector<CovGroupTile> tiles;
+    for (size_t li = 0; li < ld.size(); ++li) {
+        const CovGroupLayer& c = ld[li];
+        const int chunks = (int)((c.n_img + CG_CHUNK - 1) / CG_CHUNK);
+        pm.push_back(pm.back() + (c.needs_mean ? chunks : 0));
+        pa.push_back(pa.back() + chunks);
+        ps.push_back(ps.back() + ((c.Lp / 8 + 3) / 4) * (c.Dp / 64));
+        const int nt = cov2_tiles(c.Dp);
+        for (int t = 0; t < nt; ++t) {
+            int rb0, cb0, mb;
+            cov2_tile_of(t, c.Dp, rb0, cb0, mb);
+            tiles.push_back(CovGroupTile{(int)li, rb0, cb0, mb});
+        }
+        P->flops_upper += (double)c.g.L * c.g.D * (c.g.D + 128.0);
+    }
+    // longest contraction first: in-order dispatch is then LPT list scheduling on the one-workgroup CUs
+    std::stable_sort(tiles.begin(), tiles.end(), [&](const CovGroupTile& a, const CovGroupTile& b) {
+        const long ca = (long)ld[a.layer].Lp * a.mb, cb = (long)ld[b.layer].Lp * b.mb;
+        return ca > cb;
+    });
+    P->mean_units = pm.back();
+    P->amax_units = pa.back();
+    P->split_units = ps.back();
+    P->n_tiles = (int)tiles.size();
+    P->dyn_bytes = align256((size_t)std::max(1, P->n_group) * (2 * sizeof(void*) + sizeof(int)));
+#define COVP_HIP(call)                                                                               \
+    do {                                                                                             \
+        hipError_t e_ = (call);                                                                      \
+        if (e_ != hipSuccess) {                                                                      \
+            nsgp_cov_plan_destroy(P);                                                                \
+            return fail(NSGP_ERR_HIP, "%s failed: %s", #call, hipGetErrorString(e_));                \
+        }                                                                                            \
+    } while (0)
+    if (P->n_group > 0) {
+        COVP_HIP(hipMalloc(&P->d_layers, sizeof(CovGroupLayer) * ld.size()));
+        COVP_HIP(hipMemcpy(P->d_layers, ld.data(), sizeof(CovGroupLayer) * ld.size(), hipMemcpyHostToDevice));
+        COVP_HIP(hipMalloc(&P->d_tiles, sizeof(CovGroupTile) * tiles.size()));
+        COVP_HIP(hipMemcpy(P->d_tiles, tiles.data(), sizeof(CovGroupTile) * tiles.size(), hipMemcpyHostToDevice));
+        std::vector<int> prefix(pm);
+        prefix.insert(prefix.end(), pa.begin(), pa.end());
+        prefix.insert(prefix.end(), ps.begin(), ps.end());
+        COVP_HIP(hipMalloc(&P->d_prefix, sizeof(int) * prefix.size()));
+        COVP_HIP(hipMemcpy(P->d_prefix, prefix.data(), sizeof(int) * prefix.size(), hipMemcpyHostToDevice));
+        for (int s = 0; s < 4; ++s) {
+            COVP_HIP(hipHostMalloc(reinterpret_cast<void**>(&P->h_dyn[s]), P->dyn_bytes, hipHostMallocDefault));
+            COVP_HIP(hipMalloc(reinterpret_cast<void**>(&P->d_dyn[s]), P->dyn_bytes));
+            COVP_HIP(hipEventCreateWithFlags(&P->ev[s], hipEventDisableTiming));
+        }
+        COVP_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(nsgp_cov_group_syrk_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, V2_SMEM_BYTES));
+    }
+#undef COVP_HIP
+    *out = P;
+    return NSGP_OK;
+}
+
+extern "C" size_t nsgp_cov_plan_workspace_bytes(const nsgp_cov_plan_t* P) { return P ? P->ws_bytes : 0; }
+
+extern "C" int nsgp_cov_plan_routes(const nsgp_cov_plan_t* P, int* routes, int n) {
+    if (!P || !routes || n != P->n) return fail(NSGP_ERR_INVALID, "nsgp_cov_plan_routes: bad argument");
+    for (int i = 0; i < n; ++i) routes[i] = P->route[i] >= 0 ? 1 : 0;
+    return NSGP_OK;
+}
+
+extern "C" int nsgp_cov_plan_stats(const nsgp_cov_plan_t* P, int* n_grouped, int* n_tiles, double* upper_flops) {
+    if (!P) return fail(NSGP_ERR_INVALID, "nsgp_cov_plan_stats: null plan");
+    if (n_grouped) *n_grouped = P->n_group;
+    if (n_tiles) *n_tiles = P->n_tiles;
+    if (upper_flops) *upper_flops = P->flops_upper;
+    return NSGP_OK;
+}
+
+extern "C" int nsgp_cov_plan_run(nsgp_cov_plan_t* P, const float* const* x, float* const* cov, const int* accumulate, void* workspace,
+                                 size_t workspace_bytes, void* stream_) {
+    if (!P || !x || !cov || !accumulate) return fail(NSGP_ERR_INVALID, "nsgp_cov_plan_run: null argument");
+    if (P->n_group == 0) return NSGP_OK;
+    if (!workspace || workspace_bytes < P->ws_bytes) return fail(NSGP_ERR_WORKSPACE, "nsgp_cov_plan_run: workspace %zu < %zu", workspace_bytes, P->ws_bytes);
+    if (!aligned16(workspace)) return fail(NSGP_ERR_INVALID, "nsgp_cov_plan_run: workspace must be 16-byte aligned");
+    hipStream_t stream = static_cast<hipStream_t>(stream_);
+    const int s = P->slot;
+    P->slot = (s + 1) % 4;
+    if (P->ev_used[s]) NSGP_HIP(hipEventSynchronize(P->ev[s]));
+    const int ng = P->n_group;
+    const float** hx = reinterpret_cast<const float**>(P->h_dyn[s]);
+    float** hc = reinterpret_cast<float**>(P->h_dyn[s]) + ng;
+    int* ha = reinterpret_cast<int*>(reinterpret_cast<float**>(P->h_dyn[s]) + 2 * ng);
+    for (int i = 0; i < P->n; ++i) {
+        const int gi = P->route[i];
+        if (gi < 0) continue;
+        if (!x[i] || !cov[i]) return fail(NSGP_ERR_INVALID, "nsgp_cov_plan_run: layer %d: null input or covariance", i);
+        hx[gi] = x[i];
+        hc[gi] = cov[i];
+        ha[gi] = accumulate[i];
+    }
+    NSGP_HIP(hipMemcpyAsync(P->d_dyn[s], P->h_dyn[s], P->dyn_bytes, hipMemcpyHostToDevice, stream));
+    char* ws = static_cast<char*>(workspace);
+    unsigned* amax = reinterpret_cast<unsigned*>(ws + P->amax_off);
+    NSGP_HIP(hipMemsetAsync(amax, 0, sizeof(unsigned) * ng, stream));
+    const int* pm = P->d_prefix, *pa = P->d_prefix + (ng + 1), *ps = P->d_prefix + 2 * (ng + 1);
+    if (P->mean_units > 0) {
+        hipLaunchKernelGGL(nsgp_cov_group_mean_kernel, dim3(P->mean_units), dim3(256), 0, stream, P->d_layers, pm, ng, (const void*)P->d_dyn[s], ws);
+        NSGP_LAUNCH_CHECK();
+    }
+    hipLaunchKernelGGL(nsgp_cov_group_amax_kernel, dim3(P->amax_units), dim3(256), 0, stream, P->d_layers, pa, ng, (const void*)P->d_dyn[s], (const char*)ws, amax);
+    NSGP_LAUNCH_CHECK();
+    hipLaunchKernelGGL(nsgp_cov_group_split_kernel, dim3(P->split_units), dim3(256), 0, stream, P->d_layers, ps, ng, (const void*)P->d_dyn[s], ws, (const unsigned*)amax);
+    NSGP_LAUNCH_CHECK();
+    hipLaunchKernelGGL(nsgp_cov_group_syrk_kernel, dim3(P->n_tiles), dim3(V2L_THREADS), V2_SMEM_BYTES, stream, P->d_tiles, P->d_layers, ng,
+                       (const void*)P->d_dyn[s], (const char*)ws, (const unsigned*)amax);
+    NSGP_LAUNCH_CHECK();
+    NSGP_HIP(hipEventRecord(P->ev[s], stream));
+    P->ev_used[s] = true;
     return NSGP_OK;
 }
 

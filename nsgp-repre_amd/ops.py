@@ -158,6 +158,75 @@ def cov_workspace_bytes(cin, H, W, kernel_size, stride, padding) -> int:
                                         padding[0], padding[1])
 
 
+class CovGroupPlan:
+    """All hooked convolutions of ONE forward in five launches (``nsgp_cov_plan_*``, csrc/covariance.hip "grouped pass").
+
+    ``geoms``: one ``(batch, cin, h, w, kernel_size, stride, padding)`` per layer.  ``routes[i]`` says whether layer i rides in the
+    grouped launches (True) or has to go through ``cov_accumulate_conv2d`` (False: D not a multiple of 64).  ``run(xs, covs)``
+    assigns (``covs[i] is None``: a fresh [D x D] tensor is made) or accumulates in place, and returns the list of covariances
+    (entries of route-False layers are passed through untouched).  ``close()`` releases the plan's device tables on the calling
+    thread; nothing is released from a finaliser."""
+
+    def __init__(self, geoms, device):
+        lib = _lib.load_library()
+        self.geoms = [tuple(g) for g in geoms]
+        self.n = len(self.geoms)
+        arr = (_lib.CovGeom * self.n)()
+        self.D = []
+        for a, (b, cin, h, w, k, s, p) in zip(arr, self.geoms):
+            a.batch, a.cin, a.h, a.w, a.kh, a.kw, a.sh, a.sw, a.ph, a.pw = b, cin, h, w, k[0], k[1], s[0], s[1], p[0], p[1]
+            self.D.append(cin * k[0] * k[1])
+        self._handle = C.c_void_p()
+        with torch.cuda.device(device):
+            _lib.check(lib.nsgp_cov_plan_create(C.byref(self._handle), arr, self.n), "nsgp_cov_plan_create")
+        r = (C.c_int * self.n)()
+        _lib.check(lib.nsgp_cov_plan_routes(self._handle, r, self.n), "nsgp_cov_plan_routes")
+        self.routes = [bool(v) for v in r]
+        self.workspace_bytes = int(lib.nsgp_cov_plan_workspace_bytes(self._handle))
+        ng, nt, fl = C.c_int(), C.c_int(), C.c_double()
+        _lib.check(lib.nsgp_cov_plan_stats(self._handle, C.byref(ng), C.byref(nt), C.byref(fl)), "nsgp_cov_plan_stats")
+        self.n_grouped, self.n_tiles, self.upper_flops = ng.value, nt.value, fl.value
+        self.device = device
+        self._ws = None
+
+    def run(self, xs, covs):
+        if self._handle is None:
+            raise RuntimeError("CovGroupPlan is closed")
+        lib = _lib.load_library()
+        if len(xs) != self.n or len(covs) != self.n:
+            raise ValueError("one input and one covariance slot per layer of the plan")
+        xp, cp, acc = (C.c_void_p * self.n)(), (C.c_void_p * self.n)(), (C.c_int * self.n)()
+        out, seen = list(covs), set()
+        for i, (x, c, g, ok) in enumerate(zip(xs, covs, self.geoms, self.routes)):
+            if not ok:
+                continue
+            if tuple(x.shape) != (g[0], g[1], g[2], g[3]):
+                raise ValueError(f"layer {i}: input shape {tuple(x.shape)} does not match the plan's {g[:4]}")
+            xp[i] = _dev(x, "x").value
+            acc[i] = int(c is not None)
+            if c is None:
+                c = out[i] = torch.empty(self.D[i], self.D[i], dtype=torch.float32, device=x.device)
+            elif tuple(c.shape) != (self.D[i], self.D[i]):
+                raise ValueError(f"layer {i}: cov shape {tuple(c.shape)} != ({self.D[i]},{self.D[i]})")
+            if c.data_ptr() in seen:
+                raise ValueError("the covariances of one grouped run must be distinct buffers")
+            seen.add(c.data_ptr())
+            cp[i] = _dev(c, "cov").value
+        if self._ws is None or self._ws.numel() < self.workspace_bytes:
+            self._ws = torch.empty(max(self.workspace_bytes, 16), dtype=torch.uint8, device=self.device)
+        _lib.check(lib.nsgp_cov_plan_run(self._handle, xp, cp, acc, C.c_void_p(self._ws.data_ptr()), self._ws.numel(), _stream()), "nsgp_cov_plan_run")
+        for i, (c, ok) in enumerate(zip(covs, self.routes)):
+            if ok and c is not None:
+                _touched(c)
+        return out
+
+    def close(self):
+        if self._handle is not None:
+            h, self._handle = self._handle, None
+            _lib.check(_lib.load_library().nsgp_cov_plan_destroy(h), "nsgp_cov_plan_destroy")
+            self._ws = None
+
+
 def cov_accumulate_linear(x: torch.Tensor, cov: torch.Tensor = None) -> torch.Tensor:
     """Linear branch, runner:901-902: ``X = mean(x, 0, keepdim)``; ``C (+)= X^T X``."""
     lib = _lib.load_library()

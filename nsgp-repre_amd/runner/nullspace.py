@@ -71,7 +71,10 @@ class CovarianceStreams:
     hooked module) is pinned to side stream ``i % n``: its launches are ordered behind the producer of its input (the
     stream that calls ``run``) and behind the previous accumulations into the same C (same stream, always), and overlap
     the other layers'.  Every stream owns its workspace.  ``join()`` makes the calling stream wait for all of them --
-    before the covariances are read (all-reduce, save, eigendecomposition).  Results are bitwise what one stream gives."""
+    before the covariances are read (all-reduce, save, eigendecomposition).  Results are bitwise what one stream gives.
+    CONSTRAINT: the main stream does not wait for the side streams until ``join()``; the activation must not be written in place
+    after the hooked convolution (true of the detectors here; an arbitrary model with an in-place op on a convolution's input would
+    race) -- ``n_streams = 1`` removes the concurrency.  Since round 3 only the layers the grouped pass cannot take run this way."""
 
     def __init__(self, n_streams: int = 4):
         self.n = max(1, int(n_streams))
@@ -118,7 +121,7 @@ class CovarianceCollector:
     (``remove()`` does) before reading ``fea_in``.  ``fea_in`` has the reference's layout:
     ``{module_name + '.weight': [D x D] fp32}``."""
 
-    def __init__(self, model: nn.Module, ignore_keys: Sequence[str], n_streams: int = 4):
+    def __init__(self, model: nn.Module, ignore_keys: Sequence[str], n_streams: int = 4, grouped: bool = True):
         self.model = unwrap(model)
         self.ignore_keys = list(ignore_keys)
         self.fea_in: Dict[str, torch.Tensor] = {}
@@ -127,6 +130,13 @@ class CovarianceCollector:
         self._handles = []
         self._workspace = None
         self._streams = CovarianceStreams(n_streams) if n_streams > 1 else None
+        #: GROUPED pass (default on the GPU): the hooks of the convolutions whose D = Cin*kh*kw is a multiple of 64 only stash their
+        #: input; ``flush()`` -- called by ``cal_fea_in`` after every forward, by ``join()`` and ``remove()`` -- accumulates all of
+        #: them in five launches (``ops.CovGroupPlan``: one tile table over all layers, no split-K, no reduce).  The other layers
+        #: (the 7x7 stem, Linear) are accumulated at hook time as before, on the side streams.  False = every layer at hook time.
+        self.grouped = grouped
+        self._pending = []
+        self._plans = {}
 
     def hooked_modules(self):
         # every module that has a `.weight` and is not ignored (runner:723-724); only Conv2d and
@@ -142,7 +152,8 @@ class CovarianceCollector:
         return self
 
     def join(self):
-        """The current stream waits for every side stream: call before reading ``fea_in``."""
+        """Everything stashed is accumulated and the current stream waits for every side stream: call before reading ``fea_in``."""
+        self.flush()
         if self._streams is not None:
             self._streams.join()
 
@@ -151,6 +162,41 @@ class CovarianceCollector:
         for h in self._handles:
             h.remove()
         self._handles = []
+
+    def close(self):
+        """Release the grouped plans' device tables (explicitly, on the calling thread)."""
+        for plan in self._plans.values():
+            plan.close()
+        self._plans = {}
+
+    @torch.no_grad()
+    def flush(self):
+        """Accumulate the inputs stashed since the last flush: ONE grouped run for the first occurrence of every layer, the
+        single-layer path (in stream order) for anything else (a module called twice in one forward; a layer the plan declines)."""
+        if not self._pending:
+            return
+        pending, self._pending = self._pending, []
+        first, rest, seen = [], [], set()
+        for n, x, k, s, p, version in pending:
+            if x._version != version:
+                raise RuntimeError(f"{n}: the input of this convolution was modified in place after the convolution ran; the grouped covariance "
+                                   "pass reads activations at the end of the forward -- use CovarianceCollector(..., grouped=False)")
+            (rest if n in seen else first).append((n, x, k, s, p))
+            seen.add(n)
+        geoms = tuple((x.shape[0], x.shape[1], x.shape[2], x.shape[3], k, s, p) for _n, x, k, s, p in first)
+        dev = first[0][1].device
+        plan = self._plans.get((geoms, dev))
+        if plan is None:
+            plan = self._plans[(geoms, dev)] = ops.CovGroupPlan(geoms, dev)
+        covs = plan.run([x for _n, x, _k, _s, _p in first], [self.fea_in.get(n) for n, *_ in first])
+        for (n, x, k, s, p), c, ok in zip(first, covs, plan.routes):
+            if ok:
+                self.fea_in[n] = c
+            else:
+                rest.insert(0, (n, x, k, s, p))
+        for n, x, k, s, p in rest:
+            nbytes = ops.cov_workspace_bytes(x.shape[1], x.shape[2], x.shape[3], k, s, p)
+            self.fea_in[n] = ops.cov_accumulate_conv2d(x, k, s, p, self.fea_in.get(n), self._ws(nbytes, x.device))
 
     def _ws(self, nbytes, device):
         if self._workspace is None or self._workspace.numel() < nbytes or self._workspace.device != device:
@@ -167,6 +213,11 @@ class CovarianceCollector:
         elif isinstance(module, nn.Conv2d):
             x = x.detach().float().contiguous()
             k, s, p = module.kernel_size, module.stride, module.padding
+            if self.grouped and x.is_cuda and (x.shape[1] * k[0] * k[1]) % 64 == 0:
+                # accumulated by flush(), with all the others.  The activation is read AFTER the rest of the forward: an in-place op on
+                # a convolution's input behind the convolution would be seen -- the tensor's version counter is checked at flush
+                self._pending.append((name, x, tuple(k), tuple(s), tuple(p), x._version))
+                return None
             nbytes = ops.cov_workspace_bytes(x.shape[1], x.shape[2], x.shape[3], k, s, p)
             if self._streams is None or not x.is_cuda:
                 self.fea_in[name] = ops.cov_accumulate_conv2d(x, k, s, p, self.fea_in.get(name), self._ws(nbytes, x.device))
@@ -192,8 +243,10 @@ def cal_fea_in(model: nn.Module, batches: Iterable, ignore_keys: Sequence[str], 
                 forward(net, batch)
             else:
                 net(batch)
+            collector.flush()           # one grouped run per forward: the stashed activations are released here
     finally:
         collector.remove()
+        collector.close()
         net.train(was_training)
     fea_in = collector.fea_in
     D.barrier()

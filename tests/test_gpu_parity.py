@@ -342,7 +342,63 @@ _TRUE_SIZE = {   # (cin, kernel, stride, pad, H, W) at an 800 x 1344 padded imag
 _cov_true = {}
 
 
-@pytest.mark.parametrize("mode", [0, 2, 3])
+def test_grouped_covariance_pass_vs_single_layer_path_and_oracle(N, dev):
+    """The grouped pass (ops.CovGroupPlan: all layers of one forward in five launches, one tile table, no split-K, direct epilogue)
+    on a mixed bag of geometries -- 1x1 / 3x3, strides 1 / 2, padding, batch 1 / 2 / 16 (batch mean first), D = 64 ... 1152, an L that is
+    not a multiple of 32, a D that pads to the next 128 -- against the oracle's unfold + mm (1e-5 per row), bit-symmetric, bitwise
+    reproducible run to run, accumulation over a second batch, and the layer the tile cannot take (D = 147) routed to the
+    single-layer entry point."""
+    from nsgp_repre_amd import ops
+    geoms = [(1, 64, 40, 56, (1, 1), (1, 1), (0, 0)), (2, 64, 40, 56, (3, 3), (1, 1), (1, 1)), (1, 128, 20, 28, (3, 3), (2, 2), (1, 1)),
+             (16, 192, 9, 13, (1, 1), (1, 1), (0, 0)), (1, 256, 20, 28, (1, 1), (2, 2), (0, 0)), (2, 320, 10, 14, (1, 1), (1, 1), (0, 0)),
+             (1, 3, 64, 64, (7, 7), (2, 2), (3, 3))]
+    g = torch.Generator().manual_seed(12)
+    xs = [(torch.randn(b, c, h, w, generator=g).abs() * torch.pow(10.0, -2.0 * (torch.arange(c) % 5) / 4.0).view(1, c, 1, 1)) for b, c, h, w, *_ in geoms]
+    plan = ops.CovGroupPlan(geoms, dev)
+    assert plan.routes == [True] * 6 + [False] and plan.n_grouped == 6
+    xd = [x.to(dev) for x in xs]
+    covs = plan.run(xd, [None] * len(geoms))
+    again = plan.run(xd, [None] * len(geoms))
+    for i, (x, gm) in enumerate(zip(xs, geoms)):
+        if not plan.routes[i]:
+            assert covs[i] is None
+            continue
+        ref = O.cov_conv2d(x, gm[4], gm[5], gm[6])
+        assert _row_rel(covs[i], ref) <= REL and _rel(covs[i], ref) <= REL, (i, _row_rel(covs[i], ref))
+        assert torch.equal(covs[i], covs[i].t().contiguous()), i
+        assert torch.equal(covs[i], again[i]), (i, "not reproducible")
+    # second batch: accumulate in place (the first occurrence assigned)
+    x2 = [(x * 0.5 + 0.1).to(dev) for x in xs]
+    acc = plan.run(x2, [c.clone() if c is not None else None for c in covs])
+    for i, (x, gm) in enumerate(zip(xs, geoms)):
+        if plan.routes[i]:
+            ref = O.cov_conv2d(x, gm[4], gm[5], gm[6]) + O.cov_conv2d(x * 0.5 + 0.1, gm[4], gm[5], gm[6])
+            assert _rel(acc[i], ref) <= REL, i
+    with pytest.raises(ValueError):
+        plan.run(xd, [covs[0]] * len(geoms))        # the covariances of one run must be distinct buffers
+    plan.close()
+    with pytest.raises(RuntimeError):
+        plan.run(xd, [None] * len(geoms))
+    # through the hooks: grouped (default) and hook-time collectors agree with each other within the gate, both with the oracle
+    import torch.nn as nn
+    net = nn.Sequential(nn.Conv2d(64, 64, 3, padding=1), nn.ReLU(), nn.Conv2d(64, 128, 1), nn.ReLU(), nn.Conv2d(128, 64, 3, stride=2, padding=1)).to(dev)
+    xin = torch.randn(2, 64, 24, 32, generator=g).abs().to(dev)
+    res = {}
+    for grouped in (True, False):
+        col = N.runner.CovarianceCollector(net, [], grouped=grouped).register()
+        with torch.no_grad():
+            net(xin)
+            col.flush()
+            net(xin * 2)
+        col.remove()
+        col.close()
+        res[grouped] = col.fea_in
+    assert sorted(res[True]) == sorted(res[False]) == ["0.weight", "2.weight", "4.weight"]
+    for k in res[True]:
+        assert _rel(res[True][k], res[False][k]) <= REL, k
+
+
+@pytest.mark.parametrize("mode", [0, 2, 3, 4])
 @pytest.mark.parametrize("name", list(_TRUE_SIZE))
 def test_covariance_at_true_size(N, dev, name, mode):
     """full-size covariance parity was unpinned (tests stopped at 64 x 96 inputs; the 7 x 7 stem differed from
@@ -359,11 +415,21 @@ def test_covariance_at_true_size(N, dev, name, mode):
     g = torch.Generator().manual_seed(cin + k)
     x = torch.randn(1, cin, H, W, generator=g).abs() * torch.pow(10.0, -3.0 * (torch.arange(cin) % 8) / 7.0).view(1, cin, 1, 1)
     xd = x.to(dev)
-    prev = ops.cov_set_split_mfma(mode)
-    try:
-        cov = ops.cov_accumulate_conv2d(xd, (k, k), (st, st), (pd, pd))
-    finally:
-        ops.cov_set_split_mfma(prev)
+    if mode == 4:       # the grouped pass (what cal_fea_in runs since round 3): one tile table, no split-K, direct epilogue
+        plan = ops.CovGroupPlan([(1, cin, H, W, (k, k), (st, st), (pd, pd))], dev)
+        if not plan.routes[0]:
+            assert (cin * k * k) % 64 != 0       # the 7x7 stem stays on the single-layer entry point
+            plan.close()
+            return
+        cov = plan.run([xd], [None])[0]
+        torch.cuda.synchronize()
+        plan.close()
+    else:
+        prev = ops.cov_set_split_mfma(mode)
+        try:
+            cov = ops.cov_accumulate_conv2d(xd, (k, k), (st, st), (pd, pd))
+        finally:
+            ops.cov_set_split_mfma(prev)
     X64 = F.unfold(xd.double(), k, padding=pd, stride=st)[0].t().contiguous()        # [L x D] fp64
     ref64 = X64.t() @ X64
     del X64
@@ -371,7 +437,7 @@ def test_covariance_at_true_size(N, dev, name, mode):
     if key not in _cov_true:
         _cov_true[key] = O.cov_conv2d(x, (k, k), (st, st), (pd, pd))                   # the oracle, once per layer
     orc = _cov_true[key].to(dev)
-    rec = dict(layer=name, path={0: "f32", 2: "f16x2", 3: "f16x2-gather"}[mode], L=int((H + 2 * pd - k) // st + 1) * int((W + 2 * pd - k) // st + 1), D=cin * k * k,
+    rec = dict(layer=name, path={0: "f32", 2: "f16x2", 3: "f16x2-gather", 4: "grouped"}[mode], L=int((H + 2 * pd - k) // st + 1) * int((W + 2 * pd - k) // st + 1), D=cin * k * k,
                ours_vs_fp64_tensor_rel=_rel(cov, ref64), ours_vs_fp64_row_rel=_row_rel(cov, ref64),
                oracle_vs_fp64_tensor_rel=_rel(orc, ref64), oracle_vs_fp64_row_rel=_row_rel(orc, ref64),
                ours_vs_oracle_tensor_rel=_rel(cov, orc), ours_vs_oracle_row_rel=_row_rel(cov, orc))
@@ -394,6 +460,17 @@ def test_covariance_at_true_size(N, dev, name, mode):
         assert rec["elbow"] == e64, rec
     else:
         assert rec["elbow"] in (wobble | {e64}), rec
+    if mode == 4:
+        # the route a layer takes is decided by rule (D % 64 == 0 -> grouped pass), and its INTEGER must be the fp32 path's: the rank
+        # of round 2's gather kernel (114 where fp32 / fp64 / the oracle say 115 on the rank-deficient layer4 case) cannot come back
+        prev = ops.cov_set_split_mfma(0)
+        try:
+            cov32 = ops.cov_accumulate_conv2d(xd, (k, k), (st, st), (pd, pd))
+        finally:
+            ops.cov_set_split_mfma(prev)
+        e32 = int(elbow_index(torch.linalg.eigvalsh(cov32.double()).abs().flip(0).float().cpu().numpy(), 0.0, "sgd"))
+        rec["elbow_fp32_path"] = e32
+        assert rec["elbow"] == e32, rec
     out_dir = os.environ.get("NSGP_REPORT_DIR")
     if out_dir:
         os.makedirs(out_dir, exist_ok=True)
