@@ -711,6 +711,8 @@ struct CovGroupLayer {
 };
 struct CovGroupTile {
     int layer, rb0, cb0, mb;
+    int step0, nsteps;       // the k32 steps this workgroup contracts
+    long slab;               // >= 0: index of the 256 x 128 slab this K range writes (long contractions are cut: see CG_MAX_STEPS); -1: direct epilogue
 };
 
 __device__ __forceinline__ int cov_group_find(const int* __restrict__ prefix, int n, int unit) {
@@ -720,6 +722,11 @@ __device__ __forceinline__ int cov_group_find(const int* __restrict__ prefix, in
 }
 
 constexpr int CG_CHUNK = 256 * 16;       // elements per workgroup of the mean / amax launches
+// A tile's contraction is ONE fp32 accumulator chain: over L = 67,200 positions (2,100 steps) its rounding reached 9.7e-6 of a row's
+// maximum against fp64 -- the whole 1e-5 gate (profiles/r03/covariance_true_size.json, first form).  Contractions longer than this many
+// steps are therefore cut into equal K ranges whose slabs the ordered reduce of the single-layer path sums (a blocked summation:
+// 2.5e-6); that concerns the 13 layers of an R-50-FPN that see the stride-4 feature map, everything else writes C directly.
+constexpr int CG_MAX_STEPS = 600;
 
 // dyn: [x pointers n][cov pointers n][accumulate flags n]
 __device__ __forceinline__ const float* cg_x(const void* dyn, int i) { return reinterpret_cast<const float* const*>(dyn)[i]; }
@@ -804,18 +811,30 @@ static_assert(256 * CG_TLD * 4 <= V2_SMEM_BYTES, "the epilogue tile must fit the
 
 __global__ __launch_bounds__(V2L_THREADS, 3) void nsgp_cov_group_syrk_kernel(const CovGroupTile* __restrict__ tiles, const CovGroupLayer* __restrict__ layers,
                                                                             int n, const void* __restrict__ dyn, const char* __restrict__ ws,
-                                                                            const unsigned* __restrict__ amax) {
+                                                                            const unsigned* __restrict__ amax, float* __restrict__ slabs) {
     extern __shared__ __attribute__((aligned(16))) char smem_c[];
     const CovGroupTile t = tiles[blockIdx.x];
     const CovGroupLayer L = layers[t.layer];
     const void* xt = ws + L.xt_off;
     f32x16 acc[2][2];
     zero_acc(acc);
-    if (t.mb == 4) gemm_tile_f16x2_v2l<4>(xt, t.rb0, xt, t.cb0, L.Lp, smem_c, acc);
-    else gemm_tile_f16x2_v2l<2>(xt, t.rb0, xt, t.cb0, L.Lp, smem_c, acc);
-    // every wave is back (the loaders too) and the ring is free: park the unscaled 256 (128) x 128 block in LDS
-    float* T = reinterpret_cast<float*>(smem_c);
+    if (t.mb == 4) gemm_tile_f16x2_v2l<4>(xt, t.rb0, xt, t.cb0, L.Lp, smem_c, acc, t.step0, t.nsteps);
+    else gemm_tile_f16x2_v2l<2>(xt, t.rb0, xt, t.cb0, L.Lp, smem_c, acc, t.step0, t.nsteps);
+    // every wave is back (the loaders too) and the ring is free
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (t.slab >= 0) {                                           // one K range of a long contraction: raw partial sums to its slab
+        if (wave >= 2 * t.mb) return;
+        float* smem = reinterpret_cast<float*>(smem_c);
+        float* out = slabs + (size_t)t.slab * (256 * 128);
+        acc_to_lds(smem, acc);
+        __builtin_amdgcn_s_waitcnt(0xc07f);
+        for_each_row4(smem, [&](int r, int col, float4 v) {
+            *(gf32x4*)(out + r * 128 + col) = f32x4{v.x, v.y, v.z, v.w};
+        });
+        return;
+    }
+    // park the unscaled 256 (128) x 128 block in LDS
+    float* T = reinterpret_cast<float*>(smem_c);
     const float sc = f2_scale_from_amax_bits(amax[t.layer]);
     const float unscale = (1.0f / sc) * (1.0f / sc);
     if (wave < 2 * t.mb) {
@@ -886,6 +905,9 @@ struct nsgp_cov_plan {
     bool ev_used[4] = {false, false, false, false};
     int slot = 0;
     double flops_upper = 0;          // sum over grouped layers of L * D * (D + 128): the upper-triangle work actually needed
+    size_t slab_off = 0;
+    struct SplitLayer { int group_index, D, Dp, S; size_t slab_base; };   // layers whose contraction is cut into S K ranges
+    std::vector<SplitLayer> split_layers;
 };
 
 namespace nsgp {
@@ -954,25 +976,34 @@ extern "C" int nsgp_cov_plan_create(nsgp_cov_plan_t** out, const nsgp_cov_geom_t
     P->ws_bytes = off;
     P->n_group = (int)ld.size();
     std::vector<CovGroupTile> tiles;
+    size_t n_slabs = 0;
     for (size_t li = 0; li < ld.size(); ++li) {
         const CovGroupLayer& c = ld[li];
         const int chunks = (int)((c.n_img + CG_CHUNK - 1) / CG_CHUNK);
         pm.push_back(pm.back() + (c.needs_mean ? chunks : 0));
         pa.push_back(pa.back() + chunks);
         ps.push_back(ps.back() + ((c.Lp / 8 + 3) / 4) * (c.Dp / 64));
-        const int nt = cov2_tiles(c.Dp);
+        const int nt = cov2_tiles(c.Dp), nk = c.Lp / V2_BK;
+        const int S0 = (nk + CG_MAX_STEPS - 1) / CG_MAX_STEPS, steps = (nk + S0 - 1) / S0, S = (nk + steps - 1) / steps;
+        if (S > 1) P->split_layers.push_back(nsgp_cov_plan::SplitLayer{(int)li, c.g.D, c.Dp, S, n_slabs});
         for (int t = 0; t < nt; ++t) {
             int rb0, cb0, mb;
             cov2_tile_of(t, c.Dp, rb0, cb0, mb);
-            tiles.push_back(CovGroupTile{(int)li, rb0, cb0, mb});
+            if (S == 1) tiles.push_back(CovGroupTile{(int)li, rb0, cb0, mb, 0, nk, -1});
+            else
+                for (int sp = 0; sp < S; ++sp)      // slab layout of nsgp_cov_reduce_v2_kernel: [tile][range]
+                    tiles.push_back(CovGroupTile{(int)li, rb0, cb0, mb, sp * steps, std::min(steps, nk - sp * steps), (long)(n_slabs + (size_t)t * S + sp)});
         }
+        if (S > 1) n_slabs += (size_t)nt * S;
         P->flops_upper += (double)c.g.L * c.g.D * (c.g.D + 128.0);
     }
     // longest contraction first: in-order dispatch is then LPT list scheduling on the one-workgroup CUs
     std::stable_sort(tiles.begin(), tiles.end(), [&](const CovGroupTile& a, const CovGroupTile& b) {
-        const long ca = (long)ld[a.layer].Lp * a.mb, cb = (long)ld[b.layer].Lp * b.mb;
+        const long ca = (long)a.nsteps * a.mb, cb = (long)b.nsteps * b.mb;
         return ca > cb;
     });
+    P->slab_off = P->ws_bytes;
+    P->ws_bytes += align256(n_slabs * (size_t)(256 * 128) * 4);
     P->mean_units = pm.back();
     P->amax_units = pa.back();
     P->split_units = ps.back();
@@ -1059,9 +1090,19 @@ extern "C" int nsgp_cov_plan_run(nsgp_cov_plan_t* P, const float* const* x, floa
     NSGP_LAUNCH_CHECK();
     hipLaunchKernelGGL(nsgp_cov_group_split_kernel, dim3(P->split_units), dim3(256), 0, stream, P->d_layers, ps, ng, (const void*)P->d_dyn[s], ws, (const unsigned*)amax);
     NSGP_LAUNCH_CHECK();
+    float* slabs = reinterpret_cast<float*>(ws + P->slab_off);
     hipLaunchKernelGGL(nsgp_cov_group_syrk_kernel, dim3(P->n_tiles), dim3(V2L_THREADS), V2_SMEM_BYTES, stream, P->d_tiles, P->d_layers, ng,
-                       (const void*)P->d_dyn[s], (const char*)ws, (const unsigned*)amax);
+                       (const void*)P->d_dyn[s], (const char*)ws, (const unsigned*)amax, slabs);
     NSGP_LAUNCH_CHECK();
+    for (const nsgp_cov_plan::SplitLayer& sl : P->split_layers) {      // the long contractions: ordered sum of their K ranges
+        const int nb128 = sl.Dp / 128;
+        const long t128 = (long)nb128 * (nb128 + 1) / 2;
+        int bands = 2;
+        while (bands < 32 && t128 * bands < 256) bands *= 2;
+        hipLaunchKernelGGL(nsgp_cov_reduce_v2_kernel, dim3((unsigned)t128, bands), dim3(256), 0, stream, slabs + sl.slab_base * (size_t)(256 * 128), sl.D, sl.Dp, sl.S,
+                           128 / bands, hc[sl.group_index], ha[sl.group_index], (const unsigned*)(amax + sl.group_index));
+        NSGP_LAUNCH_CHECK();
+    }
     NSGP_HIP(hipEventRecord(P->ev[s], stream));
     P->ev_used[s] = true;
     return NSGP_OK;

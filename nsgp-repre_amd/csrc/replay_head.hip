@@ -25,6 +25,7 @@
 //                      and the bias gradient (ordered column sums); upstream = the slab sum (dZ2 W2) or dS Wc.
 //   rh_tn_kernel       dW[No x Ni] = dZ^T[No x Mp] X[M x Ni] on the 128 x 128 fp32 tile of gemm_core.hpp, grouped over jobs.
 #include <algorithm>
+#include <cstdlib>
 
 #include "common.hpp"
 #include "gemm_core.hpp"
@@ -483,7 +484,8 @@ static RhPlan rh_plan(int M, int N, int K) {
     p.Mpad = p.mchunks * p.MB * 32;
     p.ntn = (N + 127) / 128;
     const int nk = (K + 31) / 32;
-    int S = std::max(1, std::min(std::max(1, nk / 4), RH_TARGET_WGS / std::max(1, p.ntn * p.mchunks)));     // >= 4 k-steps per range
+    static const int target = [] { const char* e = getenv("NSGP_RH_WGS"); const int v = e ? atoi(e) : 0; return v > 0 ? v : RH_TARGET_WGS; }();   // study knob
+    int S = std::max(1, std::min(std::max(1, nk / 4), target / std::max(1, p.ntn * p.mchunks)));     // >= 4 k-steps per range
     p.per = (nk + S - 1) / S;
     p.S = (nk + p.per - 1) / p.per;
     p.grid = 8 * p.ntn * p.mchunks * ((p.S + 7) / 8);

@@ -23,8 +23,15 @@ rp = Replay()
 rp.bbox_head, rp.task_split, rp.task_id, rp.replay = head, split, 2, True
 rp.bbox_featss = torch.relu(torch.randn(K, 12544, device=dev))
 rp.tmp_label = torch.randint(0, split[1], (K,), device=dev)
-for _ in range(25):
+for _ in range(5):
     head.zero_grad(set_to_none=True)
     rp.add_replay_loss({})["replay_loss_cls"].backward()
 torch.cuda.synchronize()
-print("done")
+e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+e0.record()
+for _ in range(20):
+    head.zero_grad(set_to_none=True)
+    rp.add_replay_loss({})["replay_loss_cls"].backward()
+e1.record()
+torch.cuda.synchronize()
+print(f"K = {K}: {e0.elapsed_time(e1) / 20:.4f} ms per fused pass, back to back (NSGP_RH_WGS = {os.environ.get('NSGP_RH_WGS', 'default')})")
