@@ -716,17 +716,21 @@ struct CovGroupTile {
 };
 
 __device__ __forceinline__ int cov_group_find(const int* __restrict__ prefix, int n, int unit) {
-    int lo = 0;
-    while (lo + 1 < n && unit >= prefix[lo + 1]) ++lo;      // n <= ~120: a short uniform scan
+    int lo = 0, hi = n;                                      // the layer with prefix[lo] <= unit < prefix[lo + 1]: uniform binary search
+    while (hi - lo > 1) {
+        const int mid = (lo + hi) >> 1;
+        if (unit >= prefix[mid]) lo = mid; else hi = mid;
+    }
     return lo;
 }
 
-constexpr int CG_CHUNK = 256 * 16;       // elements per workgroup of the mean / amax launches
+constexpr int CG_CHUNK = 256 * 64;       // elements per workgroup of the mean / amax launches (64 KB of fp32)
 // A tile's contraction is ONE fp32 accumulator chain: over L = 67,200 positions (2,100 steps) its rounding reached 9.7e-6 of a row's
 // maximum against fp64 -- the whole 1e-5 gate (profiles/r03/covariance_true_size.json, first form).  Contractions longer than this many
 // steps are therefore cut into equal K ranges whose slabs the ordered reduce of the single-layer path sums (a blocked summation:
 // 2.5e-6); that concerns the 13 layers of an R-50-FPN that see the stride-4 feature map, everything else writes C directly.
 constexpr int CG_MAX_STEPS = 600;
+constexpr int CG_SPLIT_OCTETS = 16;      // l-octets per workgroup of the operand-split launch (4 per wave)
 
 // dyn: [x pointers n][cov pointers n][accumulate flags n]
 __device__ __forceinline__ const float* cg_x(const void* dyn, int i) { return reinterpret_cast<const float* const*>(dyn)[i]; }
@@ -767,8 +771,8 @@ __global__ __launch_bounds__(256) void nsgp_cov_group_amax_kernel(const CovGroup
     const long base = (long)(blockIdx.x - prefix[li]) * CG_CHUNK, end = min(base + CG_CHUNK, L.n_img);
     float am = 0.0f;
     if ((((uintptr_t)xm) & 15u) == 0 && end - base == CG_CHUNK) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
+#pragma unroll 8
+        for (int i = 0; i < CG_CHUNK / 1024; ++i) {
             const f32x4 q = *(const gf32x4*)(xm + base + 4 * (threadIdx.x + 256 * i));
             am = fmaxf(fmaxf(am, fmaxf(fabsf(q[0]), fabsf(q[1]))), fmaxf(fabsf(q[2]), fabsf(q[3])));
         }
@@ -788,22 +792,27 @@ __global__ __launch_bounds__(256) void nsgp_cov_group_split_kernel(const CovGrou
     const int li = cov_group_find(prefix, n, blockIdx.x);
     const CovGroupLayer L = layers[li];
     const int u = blockIdx.x - prefix[li];
-    const int nob = (L.Lp / 8 + 3) / 4;                      // workgroups along l (4 octets each)
+    const int nob = (L.Lp / 8 + CG_SPLIT_OCTETS - 1) / CG_SPLIT_OCTETS;      // workgroups along l
     const int ob = u % nob, db = u / nob;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int o = ob * 4 + wave;
-    if (o * 8 >= L.Lp) return;
     const float* __restrict__ xm = cg_image(L, dyn, li, ws);
     const int d = db * 64 + lane;
     const float scale = f2_scale_from_amax_bits(amax[li]);
-    f32x4 r[2];
-    r[0] = f32x4{0, 0, 0, 0};
-    r[1] = f32x4{0, 0, 0, 0};
-    if (d < L.g.D && o * 8 < L.g.L) {
-        const Patch8 pc = patch8(L.g, 1.0f / (float)L.g.Wo, o * 8, L.g.L);
-        stage8(xm, im2col_rowbase1(L.g, d), pc, r);
+    const long rowbase = im2col_rowbase1(L.g, d);
+    const float inv_wo = 1.0f / (float)L.g.Wo;
+#pragma unroll
+    for (int i = 0; i < CG_SPLIT_OCTETS / 4; ++i) {
+        const int o = ob * CG_SPLIT_OCTETS + 4 * i + wave;
+        if (o * 8 >= L.Lp) break;                            // uniform per wave
+        f32x4 r[2];
+        r[0] = f32x4{0, 0, 0, 0};
+        r[1] = f32x4{0, 0, 0, 0};
+        if (d < L.g.D && o * 8 < L.g.L) {
+            const Patch8 pc = patch8(L.g, inv_wo, o * 8, L.g.L);
+            stage8(xm, rowbase, pc, r);
+        }
+        v2_store_pieces(ws + L.xt_off, d, o, L.Lp, r[0], r[1], scale);
     }
-    v2_store_pieces(ws + L.xt_off, d, o, L.Lp, r[0], r[1], scale);
 }
 
 constexpr int CG_TLD = 129;              // floats per row of the epilogue tile: transposed reads stay conflict-free
@@ -982,7 +991,7 @@ extern "C" int nsgp_cov_plan_create(nsgp_cov_plan_t** out, const nsgp_cov_geom_t
         const int chunks = (int)((c.n_img + CG_CHUNK - 1) / CG_CHUNK);
         pm.push_back(pm.back() + (c.needs_mean ? chunks : 0));
         pa.push_back(pa.back() + chunks);
-        ps.push_back(ps.back() + ((c.Lp / 8 + 3) / 4) * (c.Dp / 64));
+        ps.push_back(ps.back() + ((c.Lp / 8 + CG_SPLIT_OCTETS - 1) / CG_SPLIT_OCTETS) * (c.Dp / 64));
         const int nt = cov2_tiles(c.Dp), nk = c.Lp / V2_BK;
         const int S0 = (nk + CG_MAX_STEPS - 1) / CG_MAX_STEPS, steps = (nk + S0 - 1) / S0, S = (nk + steps - 1) / steps;
         if (S > 1) P->split_layers.push_back(nsgp_cov_plan::SplitLayer{(int)li, c.g.D, c.Dp, S, n_slabs});

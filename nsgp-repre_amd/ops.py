@@ -11,7 +11,9 @@ from . import _lib
 
 
 def _stream():
-    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    # the raw handle of torch's current stream (torch.cuda.current_stream().cuda_stream builds a Stream object first: ~10x the cost,
+    # and the replay pass is host-bound)
+    return C.c_void_p(torch._C._cuda_getCurrentRawStream(torch.cuda.current_device()))
 
 
 def _touched(t: torch.Tensor) -> torch.Tensor:
@@ -308,7 +310,8 @@ def double_softmax_cross_entropy(scores: torch.Tensor, labels: torch.Tensor) -> 
 
 
 class _ReplayHeadLoss(torch.autograd.Function):
-    """bank -> relu(fc) -> relu(fc) -> class rows -> CE(softmax(.)) in 6 launches, its backward in 6 (csrc/replay_head.hip)."""
+    """bank -> relu(fc) -> relu(fc) -> class rows -> CE(softmax(.)) in 6 launches, its backward in 5 (csrc/replay_head.hip).  The pass
+    is host-bound (the GPU work is ~0.2 ms): one allocation per direction, raw pointers computed once."""
 
     @staticmethod
     def forward(ctx, bank, labels, w1, b1, w2, b2, wc, bc):
@@ -320,42 +323,46 @@ class _ReplayHeadLoss(torch.autograd.Function):
         nbytes = lib.repre_replay_head_workspace_bytes(K, fin, hidden, C_)
         if nbytes == 0:
             raise ValueError(f"replay head: unsupported size (rows {K} <= 512, class columns {C_} <= 256)")
-        dev = bank.device
-        ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
-        h1 = torch.empty(K, hidden, dtype=torch.float32, device=dev)
-        h2 = torch.empty(K, hidden, dtype=torch.float32, device=dev)
-        scores = torch.empty(K, C_, dtype=torch.float32, device=dev)
-        loss = torch.empty((), dtype=torch.float32, device=dev)
-        _lib.check(lib.repre_replay_head_forward(_dev(bank, "bank"), K, fin, _dev(w1, "w1"), _dev(b1, "b1"), _dev(w2, "w2"), _dev(b2, "b2"),
-                                                 _dev(wc, "wc"), _dev(bc, "bc"), hidden, C_, _dev(labels, "labels", torch.int64),
-                                                 _dev(h1, "h1"), _dev(h2, "h2"), _dev(scores, "scores"), C.c_void_p(loss.data_ptr()),
-                                                 C.c_void_p(ws.data_ptr()), nbytes, _stream()), "repre_replay_head_forward")
-        ctx.save_for_backward(bank, labels, w2, wc, h1, h2, scores)
-        ctx.ws = ws
+        for name, t, dt in (("bank", bank, torch.float32), ("labels", labels, torch.int64), ("w1", w1, torch.float32), ("b1", b1, torch.float32),
+                            ("w2", w2, torch.float32), ("b2", b2, torch.float32), ("wc", wc, torch.float32), ("bc", bc, torch.float32)):
+            _dev(t, name, dt)
+        # one buffer: [workspace | h1 | h2 | scores | loss], every piece 256-byte aligned
+        n_h, n_s = K * hidden, (K * C_ + 63) // 64 * 64
+        ws_f = (nbytes + 255) // 256 * 64
+        buf = torch.empty(ws_f + 2 * n_h + n_s + 64, dtype=torch.float32, device=bank.device)
+        h1, h2 = buf[ws_f:ws_f + n_h].view(K, hidden), buf[ws_f + n_h:ws_f + 2 * n_h].view(K, hidden)
+        scores = buf[ws_f + 2 * n_h:ws_f + 2 * n_h + K * C_].view(K, C_)
+        loss = buf[ws_f + 2 * n_h + n_s]
+        base = buf.data_ptr()
+        _lib.check(lib.repre_replay_head_forward(bank.data_ptr(), K, fin, w1.data_ptr(), b1.data_ptr(), w2.data_ptr(), b2.data_ptr(),
+                                                 wc.data_ptr(), bc.data_ptr(), hidden, C_, labels.data_ptr(),
+                                                 h1.data_ptr(), h2.data_ptr(), scores.data_ptr(), loss.data_ptr(),
+                                                 base, ws_f * 4, _stream()), "repre_replay_head_forward")
+        ctx.save_for_backward(bank, labels, w2, wc, buf)
+        ctx.dims = (K, fin, hidden, C_, ws_f, n_h, n_s)
         ctx.mark_non_differentiable(scores)
         return loss, scores
 
     @staticmethod
     def backward(ctx, grad_loss, _grad_scores):
-        bank, labels, w2, wc, h1, h2, scores = ctx.saved_tensors
+        bank, labels, w2, wc, buf = ctx.saved_tensors
         lib = _lib.load_library()
-        K, fin = bank.shape
-        hidden, C_ = w2.shape[0], wc.shape[0]
-        dev = bank.device
+        K, fin, hidden, C_, ws_f, n_h, n_s = ctx.dims
         go = grad_loss.detach().reshape(()).float().contiguous()
-        gw1 = torch.empty(hidden, fin, dtype=torch.float32, device=dev)
-        gb1 = torch.empty(hidden, dtype=torch.float32, device=dev)
-        gw2 = torch.empty(hidden, hidden, dtype=torch.float32, device=dev)
-        gb2 = torch.empty(hidden, dtype=torch.float32, device=dev)
-        gwc = torch.empty(C_, hidden, dtype=torch.float32, device=dev)
-        gbc = torch.empty(C_, dtype=torch.float32, device=dev)
-        ws = ctx.ws
-        _lib.check(lib.repre_replay_head_backward(_dev(bank, "bank"), K, fin, _dev(w2, "w2"), _dev(wc, "wc"), hidden, C_,
-                                                  _dev(labels, "labels", torch.int64), _dev(h1, "h1"), _dev(h2, "h2"), _dev(scores, "scores"),
-                                                  C.c_void_p(go.data_ptr()), _dev(gw1, "gw1"), _dev(gb1, "gb1"), _dev(gw2, "gw2"), _dev(gb2, "gb2"),
-                                                  _dev(gwc, "gwc"), _dev(gbc, "gbc"), C.c_void_p(ws.data_ptr()), ws.numel(), _stream()),
-                   "repre_replay_head_backward")
-        return None, None, gw1, gb1, gw2, gb2, gwc, gbc
+        # one buffer for the six gradients, every piece 256-byte aligned
+        sizes = (hidden * fin, hidden, hidden * hidden, hidden, C_ * hidden, C_)
+        offs, tot = [], 0
+        for n_ in sizes:
+            offs.append(tot)
+            tot += (n_ + 63) // 64 * 64
+        gbuf = torch.empty(tot, dtype=torch.float32, device=bank.device)
+        gw1, gb1, gw2, gb2, gwc, gbc = (gbuf[o:o + n_] for o, n_ in zip(offs, sizes))
+        base, gp = buf.data_ptr(), gbuf.data_ptr()
+        _lib.check(lib.repre_replay_head_backward(bank.data_ptr(), K, fin, w2.data_ptr(), wc.data_ptr(), hidden, C_, labels.data_ptr(),
+                                                  base + 4 * ws_f, base + 4 * (ws_f + n_h), base + 4 * (ws_f + 2 * n_h), go.data_ptr(),
+                                                  gp + 4 * offs[0], gp + 4 * offs[1], gp + 4 * offs[2], gp + 4 * offs[3], gp + 4 * offs[4], gp + 4 * offs[5],
+                                                  base, ws_f * 4, _stream()), "repre_replay_head_backward")
+        return (None, None, gw1.view(hidden, fin), gb1, gw2.view(hidden, hidden), gb2, gwc.view(C_, hidden), gbc)
 
 
 def replay_head_loss(bank: torch.Tensor, labels: torch.Tensor, w1, b1, w2, b2, wc, bc):
