@@ -84,7 +84,7 @@ def r50_fpn_hooked_convs(H=800, W=1344, depth=50):
     return out
 
 
-def _covariance_forward_ms(dev, depth):
+def _covariance_forward_ms(dev, depth, only_grouped=False):
     from nsgp_repre_amd import ops
     g = torch.Generator(device=dev).manual_seed(5)
     layers = r50_fpn_hooked_convs(depth=depth)
@@ -125,7 +125,7 @@ def _covariance_forward_ms(dev, depth):
         gcov = plan.run([acts[(cin, h, w)] for n, cin, k, s, p, h, w in layers], gcov)
         side.join()
     out = []
-    for fn in (forward_grouped, lambda: forward(True), lambda: forward(False)):
+    for fn in ((forward_grouped,) * 3 if only_grouped else (forward_grouped, lambda: forward(True), lambda: forward(False))):
         fn()
         torch.cuda.synchronize()
         ts = []

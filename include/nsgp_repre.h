@@ -283,24 +283,27 @@ int repre_replay_ce_backward(const float* scores, const int64_t* labels, int n_r
  * The whole per-step replay pass  (SURVEY rows a16 + a17)
  * Replaces StandardMultiPrototypeReplayHead.replay_loss, mmdet/models/roi_heads/standard_roi_replay_head.py:468-501, over
  * Shared2FCBBoxHeadTask.forward, mmdet/models/roi_heads/bbox_heads/convfc_bbox_head_task.py:235-276, and the autograd backward of
- * both (~40 library launches around one 51 MB weight pass each way) by 6 + 6 launches on the exact fp32 MFMA:
+ * both (~40 library launches around one 51 MB weight pass each way) by 6 + 5 launches on the exact fp32 MFMA:
  *     H1 = relu(bank W1^T + b1);  H2 = relu(H1 W2^T + b2);  S = H2 Wc^T + bc;  loss = mean CE(softmax(S), labels)
- * bank [n_rows x in_features] (the prototype bank: a constant, no gradient), w1 [hidden x in_features], w2 [hidden x hidden],
- * wc [n_cols x hidden] = the rows of the per-task fc_cls heads seen so far followed by the background row, stacked by the caller
- * (the reference keeps the columns [:task_split[task_id]] and the last one, head:495-497), labels int64 [n_rows].
+ * bank [n_rows x in_features] (the prototype bank: a constant, no gradient), w1 [hidden x in_features], w2 [hidden x hidden].
+ * The kept class rows -- the reference keeps the columns [:task_split[task_id]] and the last one, head:495-497 -- are the rows of the
+ * per-task fc_cls heads seen so far followed by the background head: n_heads (<= 16) weight / bias pointers with head_rows[h] rows
+ * each, read in place (no stacked copy); n_cols = the sum of head_rows.  labels int64 [n_rows].
  * forward writes h1, h2 [n_rows x hidden], scores [n_rows x n_cols] and the scalar loss (all device fp32; the caller keeps
- * h1 / h2 / scores for backward).  backward writes (not accumulates) gw1 [hidden x in_features], gb1, gw2, gb2 [hidden],
- * gwc [n_cols x hidden], gbc [n_cols] for upstream gradient *grad_out (device scalar).  Deterministic (fixed summation order).
- * n_rows <= 512, n_cols <= 256.  workspace: >= repre_replay_head_workspace_bytes(...), 16-byte aligned, shared by both calls.
+ * h1 / h2 / scores for backward).  backward writes (not accumulates) gw1 [hidden x in_features], gb1, gw2, gb2 [hidden] and, per
+ * head, gwc_heads[h] [head_rows[h] x hidden], gbc_heads[h] [head_rows[h]], for upstream gradient *grad_out (device scalar).
+ * Deterministic (fixed summation order).  n_rows <= 512, n_cols <= 256.  workspace: >= repre_replay_head_workspace_bytes(...),
+ * 16-byte aligned, shared by both calls.
  * ------------------------------------------------------------------------ */
 size_t repre_replay_head_workspace_bytes(int n_rows, int in_features, int hidden, int n_cols);
 int repre_replay_head_forward(const float* bank, int n_rows, int in_features, const float* w1, const float* b1, const float* w2,
-                              const float* b2, const float* wc, const float* bc, int hidden, int n_cols, const int64_t* labels,
-                              float* h1, float* h2, float* scores, float* loss_out, void* workspace, size_t workspace_bytes,
-                              void* stream);
-int repre_replay_head_backward(const float* bank, int n_rows, int in_features, const float* w2, const float* wc, int hidden,
-                               int n_cols, const int64_t* labels, const float* h1, const float* h2, const float* scores,
-                               const float* grad_out, float* gw1, float* gb1, float* gw2, float* gb2, float* gwc, float* gbc,
+                              const float* b2, const float* const* wc_heads, const float* const* bc_heads, const int* head_rows,
+                              int n_heads, int hidden, int n_cols, const int64_t* labels, float* h1, float* h2, float* scores,
+                              float* loss_out, void* workspace, size_t workspace_bytes, void* stream);
+int repre_replay_head_backward(const float* bank, int n_rows, int in_features, const float* w2, const float* const* wc_heads,
+                               const float* const* bc_heads, const int* head_rows, int n_heads, int hidden, int n_cols,
+                               const int64_t* labels, const float* h1, const float* h2, const float* scores, const float* grad_out,
+                               float* gw1, float* gb1, float* gw2, float* gb2, float* const* gwc_heads, float* const* gbc_heads,
                                void* workspace, size_t workspace_bytes, void* stream);
 
 /* ------------------------------------------------------------------------

@@ -73,10 +73,11 @@ SIGNATURES = {
     "repre_replay_ce_forward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "repre_replay_ce_backward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
     "repre_replay_head_workspace_bytes": (C.c_size_t, [C.c_int] * 4),
-    "repre_replay_head_forward": (C.c_int, [C.c_void_p, C.c_int, C.c_int] + [C.c_void_p] * 6 + [C.c_int, C.c_int] + [C.c_void_p] * 6
-                                  + [C.c_size_t, C.c_void_p]),
-    "repre_replay_head_backward": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int] + [C.c_void_p] * 12
-                                   + [C.c_size_t, C.c_void_p]),
+    "repre_replay_head_forward": (C.c_int, [C.c_void_p, C.c_int, C.c_int] + [C.c_void_p] * 4 + [C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_int),
+                                            C.c_int, C.c_int, C.c_int] + [C.c_void_p] * 6 + [C.c_size_t, C.c_void_p]),
+    "repre_replay_head_backward": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_int),
+                                             C.c_int, C.c_int, C.c_int] + [C.c_void_p] * 9 + [C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.c_void_p,
+                                                                                            C.c_size_t, C.c_void_p]),
     "nsgp_plan_uses_split_mfma": (C.c_int, [C.c_void_p]),
     "nsgp_plan_tile_counts": (C.c_int, [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "nsgp_cov_set_split_mfma": (C.c_int, [C.c_int]),

@@ -744,10 +744,15 @@ __global__ __launch_bounds__(256) void nsgp_cov_group_mean_kernel(const CovGroup
     const float* __restrict__ x = cg_x(dyn, li);
     float* __restrict__ xm = reinterpret_cast<float*>(ws + L.xm_off);
     const int Hp = L.H + 2 * L.ph, Wp = L.W + 2 * L.pw;
-    const long base = (long)(blockIdx.x - prefix[li]) * CG_CHUNK;
+    const long base = (long)(blockIdx.x - prefix[li]) * CG_CHUNK, end = min(base + CG_CHUNK, L.n_img);
     const long bs = (long)L.cin * L.H * L.W;
-    for (long idx = base + threadIdx.x; idx < min(base + CG_CHUNK, L.n_img); idx += 256) {
-        const int xx = (int)(idx % Wp), yy = (int)((idx / Wp) % Hp), c = (int)(idx / ((long)Wp * Hp));
+    // one division per thread, then an incremental (row, column) walk in steps of 256 elements
+    long idx = base + threadIdx.x;
+    if (idx >= end) return;
+    int row = (int)(idx / Wp), xx = (int)(idx - (long)row * Wp);      // row = c * Hp + yy
+    int c = row / Hp, yy = row - c * Hp;
+    const int qr = 256 / Wp, rr = 256 - qr * Wp;
+    for (; idx < end; idx += 256) {
         float v = 0.0f;
         if (yy >= L.ph && yy < L.ph + L.H && xx >= L.pw && xx < L.pw + L.W) {
             const long off = ((long)c * L.H + (yy - L.ph)) * L.W + (xx - L.pw);
@@ -756,6 +761,10 @@ __global__ __launch_bounds__(256) void nsgp_cov_group_mean_kernel(const CovGroup
             v = (L.batch > 1) ? s / (float)L.batch : s;
         }
         xm[idx] = v;
+        xx += rr;
+        yy += qr;
+        if (xx >= Wp) { xx -= Wp; ++yy; }
+        while (yy >= Hp) { yy -= Hp; ++c; }
     }
 }
 

@@ -215,8 +215,26 @@ __global__ __launch_bounds__(256) void rh_reduce_kernel(const float* __restrict_
 // three shuffles; the row of H sits in LDS.  Then the row's double-softmax CE term rowloss[m] = logsumexp(softmax(s_m)) -
 // softmax(s_m)[y_m] (head:499) from the scores still in LDS.
 constexpr int RS_MAX_HIDDEN = 4096;
-__global__ __launch_bounds__(256) void rh_scores_kernel(const float* __restrict__ H, int M, int hidden, const float* __restrict__ Wc,
-                                                        const float* __restrict__ bc, int C, const long long* __restrict__ labels,
+
+// The kept class rows live in the per-task fc_cls heads (tasks 1 .. task_id, then the background head): the kernels read them
+// through this table instead of a stacked copy (the torch.cat of the rows and the split of their gradient were two launches and
+// half a dozen autograd nodes per step on a host-bound pass).  Row c of the stacked view belongs to head h with row0[h] <= c < row0[h+1].
+constexpr int RH_MAX_HEADS = 16;
+struct RhHeads {
+    const float* w[RH_MAX_HEADS];
+    const float* b[RH_MAX_HEADS];
+    float* gw[RH_MAX_HEADS];
+    float* gb[RH_MAX_HEADS];
+    int row0[RH_MAX_HEADS + 1];
+    int n;
+};
+__device__ __forceinline__ int rh_head_of(const RhHeads& hd, int c) {
+    int h = 0;
+    while (h + 1 < hd.n && c >= hd.row0[h + 1]) ++h;
+    return h;
+}
+__global__ __launch_bounds__(256) void rh_scores_kernel(const float* __restrict__ H, int M, int hidden, const RhHeads hd, int C,
+                                                        const long long* __restrict__ labels,
                                                         float* __restrict__ scores, float* __restrict__ rowloss) {
     __shared__ __attribute__((aligned(16))) float hs[RS_MAX_HIDDEN];
     __shared__ float sc[RH_MAX_COLS];
@@ -226,12 +244,14 @@ __global__ __launch_bounds__(256) void rh_scores_kernel(const float* __restrict_
         for (int k = t; k < hidden; k += 256) hs[k] = H[(long)m * hidden + k];
         __syncthreads();
     }
-    const bool vec = staged && (hidden & 3) == 0 && ((uintptr_t)Wc & 15u) == 0;
+    bool vec = staged && (hidden & 3) == 0;
+    for (int h = 0; h < hd.n; ++h) vec = vec && (((uintptr_t)hd.w[h]) & 15u) == 0;
     for (int c0 = 0; c0 < C; c0 += 32) {
         const int c = c0 + cl;
         float acc = 0.0f;
         if (c < C) {
-            const float* w = Wc + (long)c * hidden;
+            const int hh = rh_head_of(hd, c);
+            const float* w = hd.w[hh] + (long)(c - hd.row0[hh]) * hidden;
             if (vec) {
                 for (int k = 4 * ks; k < hidden; k += 32) {
                     const f32x4 wv = *(const gf32x4*)(w + k);
@@ -247,7 +267,8 @@ __global__ __launch_bounds__(256) void rh_scores_kernel(const float* __restrict_
         acc += __shfl_xor(acc, 2, 64);
         acc += __shfl_xor(acc, 4, 64);
         if (ks == 0 && c < C) {
-            const float v = acc + bc[c];
+            const int hh = rh_head_of(hd, c);
+            const float v = acc + hd.b[hh][c - hd.row0[hh]];
             sc[c] = v;
             scores[(long)m * C + c] = v;
         }
@@ -286,13 +307,13 @@ __global__ __launch_bounds__(256) void rh_mean_kernel(const float* __restrict__ 
 constexpr int DZ_COLS = 16, DZ_RC = 64, DZ_THREADS = 512, DZ_GROUPS = DZ_THREADS / DZ_COLS, DZ_WACC = RH_MAX_COLS * DZ_COLS / DZ_THREADS;
 struct RhDz {
     const float* slabs; int S; int Mpad;         // MODE 0
-    const float* dS; const float* Wc; int C;     // MODE 1
+    const float* dS; int C;                      // MODE 1 (+ hd: the class heads' rows and gradient buffers)
     const float* H;                              // [M x N] the layer's OUTPUT (post-ReLU): relu'(z) = (H > 0)
     int M, N, Mp;
     float* dZ;                                   // [M x N] or null
     float* dZT;                                  // [N x Mp]
     float* db;                                   // [N]
-    float* dWc; float* dbc;                      // MODE 1: [C x N], [C]
+    RhHeads hd;                                  // MODE 1
 };
 
 template <int MODE>
@@ -304,7 +325,8 @@ __global__ __launch_bounds__(DZ_THREADS) void rh_dz_kernel(const RhDz a) {
         for (int c = t; c < a.C; c += DZ_THREADS) {
             float s = 0.0f;
             for (int m = 0; m < a.M; ++m) s += a.dS[(long)m * a.C + c];
-            a.dbc[c] = s;
+            const int hh = rh_head_of(a.hd, c);
+            a.hd.gb[hh][c - a.hd.row0[hh]] = s;
         }
         return;
     }
@@ -318,7 +340,8 @@ __global__ __launch_bounds__(DZ_THREADS) void rh_dz_kernel(const RhDz a) {
     if (MODE == 1) {
         for (int idx = t; idx < a.C * DZ_COLS; idx += DZ_THREADS) {
             const int cc = idx / DZ_COLS, col = n0 + (idx & (DZ_COLS - 1));
-            wct[idx] = (col < a.N) ? a.Wc[(long)cc * a.N + col] : 0.0f;
+            const int hh = rh_head_of(a.hd, cc);
+            wct[idx] = (col < a.N) ? a.hd.w[hh][(long)(cc - a.hd.row0[hh]) * a.N + col] : 0.0f;
         }
     }
     const long stride = (long)a.Mpad * a.N;
@@ -395,7 +418,8 @@ __global__ __launch_bounds__(DZ_THREADS) void rh_dz_kernel(const RhDz a) {
             const int idx = t + DZ_THREADS * j;
             if (idx < a.C * DZ_COLS) {
                 const int cc = idx / DZ_COLS, col = n0 + (idx & (DZ_COLS - 1));
-                if (col < a.N) a.dWc[(long)cc * a.N + col] = wacc[j];
+                const int hh = rh_head_of(a.hd, cc);
+                if (col < a.N) a.hd.gw[hh][(long)(cc - a.hd.row0[hh]) * a.N + col] = wacc[j];
             }
         }
     }
@@ -577,14 +601,34 @@ extern "C" size_t repre_replay_head_workspace_bytes(int n_rows, int in_features,
     return rh_workspace(n_rows, in_features, hidden, n_cols).total;
 }
 
+static int rh_make_heads(const char* who, RhHeads& hd, const float* const* w, const float* const* b, float* const* gw, float* const* gb,
+                         const int* rows, int n_heads, int n_cols) {
+    if (!w || !b || !rows || n_heads <= 0 || n_heads > RH_MAX_HEADS) return fail(NSGP_ERR_INVALID, "%s: 1..%d class heads expected", who, RH_MAX_HEADS);
+    hd.n = n_heads;
+    hd.row0[0] = 0;
+    for (int h = 0; h < n_heads; ++h) {
+        if (!w[h] || !b[h] || rows[h] <= 0 || (gw && (!gw[h] || !gb[h]))) return fail(NSGP_ERR_INVALID, "%s: class head %d: null pointer or no rows", who, h);
+        hd.w[h] = w[h];
+        hd.b[h] = b[h];
+        hd.gw[h] = gw ? gw[h] : nullptr;
+        hd.gb[h] = gb ? gb[h] : nullptr;
+        hd.row0[h + 1] = hd.row0[h] + rows[h];
+    }
+    if (hd.row0[n_heads] != n_cols) return fail(NSGP_ERR_INVALID, "%s: the heads hold %d rows, n_cols = %d", who, hd.row0[n_heads], n_cols);
+    return NSGP_OK;
+}
+
 extern "C" int repre_replay_head_forward(const float* bank, int n_rows, int in_features, const float* w1, const float* b1, const float* w2,
-                                         const float* b2, const float* wc, const float* bc, int hidden, int n_cols, const int64_t* labels,
+                                         const float* b2, const float* const* wc_heads, const float* const* bc_heads, const int* head_rows,
+                                         int n_heads, int hidden, int n_cols, const int64_t* labels,
                                          float* h1, float* h2, float* scores, float* loss_out, void* workspace, size_t workspace_bytes,
                                          void* stream_) {
     int rc = rh_check_dims("repre_replay_head_forward", n_rows, in_features, hidden, n_cols);
     if (rc) return rc;
-    if (!bank || !w1 || !b1 || !w2 || !b2 || !wc || !bc || !labels || !h1 || !h2 || !scores || !loss_out || !workspace)
+    if (!bank || !w1 || !b1 || !w2 || !b2 || !labels || !h1 || !h2 || !scores || !loss_out || !workspace)
         return fail(NSGP_ERR_INVALID, "repre_replay_head_forward: null argument");
+    RhHeads hd{};
+    if ((rc = rh_make_heads("repre_replay_head_forward", hd, wc_heads, bc_heads, nullptr, nullptr, head_rows, n_heads, n_cols))) return rc;
     const RhWorkspace W = rh_workspace(n_rows, in_features, hidden, n_cols);
     if (workspace_bytes < W.total) return fail(NSGP_ERR_WORKSPACE, "repre_replay_head_forward: workspace %zu < %zu bytes", workspace_bytes, W.total);
     if (!aligned16(workspace)) return fail(NSGP_ERR_INVALID, "repre_replay_head_forward: workspace must be 16-byte aligned");
@@ -596,7 +640,7 @@ extern "C" int repre_replay_head_forward(const float* bank, int n_rows, int in_f
     if ((rc = rh_launch_skinny<true>(h1, hidden, w2, hidden, slabs, n_rows, hidden, hidden, p, stream))) return rc;
     if ((rc = rh_launch_reduce(slabs, p, n_rows, hidden, b2, h2, stream))) return rc;
     float* rowloss = reinterpret_cast<float*>(static_cast<char*>(workspace) + W.rowloss);
-    hipLaunchKernelGGL(rh_scores_kernel, dim3(n_rows), dim3(256), 0, stream, h2, n_rows, hidden, wc, bc, n_cols,
+    hipLaunchKernelGGL(rh_scores_kernel, dim3(n_rows), dim3(256), 0, stream, h2, n_rows, hidden, hd, n_cols,
                        reinterpret_cast<const long long*>(labels), scores, rowloss);
     NSGP_LAUNCH_CHECK();
     hipLaunchKernelGGL(rh_mean_kernel, dim3(1), dim3(256), 0, stream, rowloss, n_rows, loss_out);
@@ -604,14 +648,18 @@ extern "C" int repre_replay_head_forward(const float* bank, int n_rows, int in_f
     return NSGP_OK;
 }
 
-extern "C" int repre_replay_head_backward(const float* bank, int n_rows, int in_features, const float* w2, const float* wc, int hidden,
+extern "C" int repre_replay_head_backward(const float* bank, int n_rows, int in_features, const float* w2, const float* const* wc_heads,
+                                          const float* const* bc_heads, const int* head_rows, int n_heads, int hidden,
                                           int n_cols, const int64_t* labels, const float* h1, const float* h2, const float* scores,
-                                          const float* grad_out, float* gw1, float* gb1, float* gw2, float* gb2, float* gwc, float* gbc,
+                                          const float* grad_out, float* gw1, float* gb1, float* gw2, float* gb2, float* const* gwc_heads,
+                                          float* const* gbc_heads,
                                           void* workspace, size_t workspace_bytes, void* stream_) {
     int rc = rh_check_dims("repre_replay_head_backward", n_rows, in_features, hidden, n_cols);
     if (rc) return rc;
-    if (!bank || !w2 || !wc || !labels || !h1 || !h2 || !scores || !grad_out || !gw1 || !gb1 || !gw2 || !gb2 || !gwc || !gbc || !workspace)
+    if (!bank || !w2 || !labels || !h1 || !h2 || !scores || !grad_out || !gw1 || !gb1 || !gw2 || !gb2 || !gwc_heads || !gbc_heads || !workspace)
         return fail(NSGP_ERR_INVALID, "repre_replay_head_backward: null argument");
+    RhHeads hd{};
+    if ((rc = rh_make_heads("repre_replay_head_backward", hd, wc_heads, bc_heads, gwc_heads, gbc_heads, head_rows, n_heads, n_cols))) return rc;
     const RhWorkspace W = rh_workspace(n_rows, in_features, hidden, n_cols);
     if (workspace_bytes < W.total) return fail(NSGP_ERR_WORKSPACE, "repre_replay_head_backward: workspace %zu < %zu bytes", workspace_bytes, W.total);
     if (!aligned16(workspace)) return fail(NSGP_ERR_INVALID, "repre_replay_head_backward: workspace must be 16-byte aligned");
@@ -633,14 +681,14 @@ extern "C" int repre_replay_head_backward(const float* bank, int n_rows, int in_
         dz_armed = dz_lds;
     }
     {   // dZ2 = (dS Wc) * (H2 > 0), its transposed copy, db2; the class heads' dWc = dS^T H2 and dbc
-        RhDz a{nullptr, 0, 0, dS, wc, n_cols, h2, M, hidden, Mp, dZ2, dZ2T, gb2, gwc, gbc};
+        RhDz a{nullptr, 0, 0, dS, n_cols, h2, M, hidden, Mp, dZ2, dZ2T, gb2, hd};
         hipLaunchKernelGGL(rh_dz_kernel<1>, dim3(nblocks + 1), dim3(DZ_THREADS), dz_lds, stream, a);
         NSGP_LAUNCH_CHECK();
     }
     RhPlan p;    // dH1 = dZ2 W2   (W2 is [hidden(k) x hidden(n)] row-major for this product)
     if ((rc = rh_launch_skinny<false>(dZ2, hidden, w2, hidden, slabs, M, hidden, hidden, p, stream))) return rc;
     {   // dZ1 = dH1 * (H1 > 0): only its transposed copy is needed (dX is not: the bank is a constant), db1
-        RhDz a{slabs, p.S, p.Mpad, nullptr, nullptr, 0, h1, M, hidden, Mp, nullptr, dZ1T, gb1, nullptr, nullptr};
+        RhDz a{slabs, p.S, p.Mpad, nullptr, 0, h1, M, hidden, Mp, nullptr, dZ1T, gb1, RhHeads{}};
         hipLaunchKernelGGL(rh_dz_kernel<0>, dim3(nblocks), dim3(DZ_THREADS), dz_lds, stream, a);
         NSGP_LAUNCH_CHECK();
     }

@@ -311,67 +311,86 @@ def double_softmax_cross_entropy(scores: torch.Tensor, labels: torch.Tensor) -> 
 
 class _ReplayHeadLoss(torch.autograd.Function):
     """bank -> relu(fc) -> relu(fc) -> class rows -> CE(softmax(.)) in 6 launches, its backward in 5 (csrc/replay_head.hip).  The pass
-    is host-bound (the GPU work is ~0.2 ms): one allocation per direction, raw pointers computed once."""
+    is host-bound (the GPU work is ~0.2 ms): one allocation per direction, raw pointers, the class heads read in place."""
 
     @staticmethod
-    def forward(ctx, bank, labels, w1, b1, w2, b2, wc, bc):
+    def forward(ctx, bank, labels, w1, b1, w2, b2, *heads):
         lib = _lib.load_library()
         K, fin = bank.shape
-        hidden, C_ = w1.shape[0], wc.shape[0]
-        if w1.shape != (hidden, fin) or w2.shape != (hidden, hidden) or wc.shape[1] != hidden:
-            raise ValueError(f"replay head shapes do not chain: bank {tuple(bank.shape)}, w1 {tuple(w1.shape)}, w2 {tuple(w2.shape)}, wc {tuple(wc.shape)}")
+        hidden = w1.shape[0]
+        hw, hb = heads[0::2], heads[1::2]
+        nh = len(hw)
+        rows = [int(w.shape[0]) for w in hw]
+        C_ = sum(rows)
+        if w1.shape != (hidden, fin) or w2.shape != (hidden, hidden) or nh == 0 or nh != len(hb) or any(w.shape[1] != hidden for w in hw):
+            raise ValueError(f"replay head shapes do not chain: bank {tuple(bank.shape)}, w1 {tuple(w1.shape)}, w2 {tuple(w2.shape)}, "
+                             f"class heads {[tuple(w.shape) for w in hw]}")
         nbytes = lib.repre_replay_head_workspace_bytes(K, fin, hidden, C_)
-        if nbytes == 0:
-            raise ValueError(f"replay head: unsupported size (rows {K} <= 512, class columns {C_} <= 256)")
-        for name, t, dt in (("bank", bank, torch.float32), ("labels", labels, torch.int64), ("w1", w1, torch.float32), ("b1", b1, torch.float32),
-                            ("w2", w2, torch.float32), ("b2", b2, torch.float32), ("wc", wc, torch.float32), ("bc", bc, torch.float32)):
-            _dev(t, name, dt)
+        if nbytes == 0 or nh > 16:
+            raise ValueError(f"replay head: unsupported size (rows {K} <= 512, class columns {C_} <= 256, heads {nh} <= 16)")
+        _dev(bank, "bank"), _dev(labels, "labels", torch.int64)
+        for i, t in enumerate((w1, b1, w2, b2) + tuple(heads)):
+            _dev(t, f"weight {i}")
         # one buffer: [workspace | h1 | h2 | scores | loss], every piece 256-byte aligned
         n_h, n_s = K * hidden, (K * C_ + 63) // 64 * 64
         ws_f = (nbytes + 255) // 256 * 64
         buf = torch.empty(ws_f + 2 * n_h + n_s + 64, dtype=torch.float32, device=bank.device)
-        h1, h2 = buf[ws_f:ws_f + n_h].view(K, hidden), buf[ws_f + n_h:ws_f + 2 * n_h].view(K, hidden)
+        base = buf.data_ptr()
         scores = buf[ws_f + 2 * n_h:ws_f + 2 * n_h + K * C_].view(K, C_)
         loss = buf[ws_f + 2 * n_h + n_s]
-        base = buf.data_ptr()
+        wp, bp, rp = (C.c_void_p * nh)(*[w.data_ptr() for w in hw]), (C.c_void_p * nh)(*[b.data_ptr() for b in hb]), (C.c_int * nh)(*rows)
         _lib.check(lib.repre_replay_head_forward(bank.data_ptr(), K, fin, w1.data_ptr(), b1.data_ptr(), w2.data_ptr(), b2.data_ptr(),
-                                                 wc.data_ptr(), bc.data_ptr(), hidden, C_, labels.data_ptr(),
-                                                 h1.data_ptr(), h2.data_ptr(), scores.data_ptr(), loss.data_ptr(),
+                                                 wp, bp, rp, nh, hidden, C_, labels.data_ptr(),
+                                                 base + 4 * ws_f, base + 4 * (ws_f + n_h), scores.data_ptr(), loss.data_ptr(),
                                                  base, ws_f * 4, _stream()), "repre_replay_head_forward")
-        ctx.save_for_backward(bank, labels, w2, wc, buf)
-        ctx.dims = (K, fin, hidden, C_, ws_f, n_h, n_s)
+        ctx.save_for_backward(bank, labels, w2, buf, *heads)
+        ctx.dims = (K, fin, hidden, C_, ws_f, n_h, n_s, rows)
         ctx.mark_non_differentiable(scores)
         return loss, scores
 
     @staticmethod
     def backward(ctx, grad_loss, _grad_scores):
-        bank, labels, w2, wc, buf = ctx.saved_tensors
+        bank, labels, w2, buf, *heads = ctx.saved_tensors
         lib = _lib.load_library()
-        K, fin, hidden, C_, ws_f, n_h, n_s = ctx.dims
+        K, fin, hidden, C_, ws_f, n_h, n_s, rows = ctx.dims
+        hw, hb = heads[0::2], heads[1::2]
+        nh = len(rows)
         go = grad_loss.detach().reshape(()).float().contiguous()
-        # one buffer for the six gradients, every piece 256-byte aligned
-        sizes = (hidden * fin, hidden, hidden * hidden, hidden, C_ * hidden, C_)
+        # one buffer for all gradients, every piece 256-byte aligned
+        sizes = [hidden * fin, hidden, hidden * hidden, hidden]
+        for r in rows:
+            sizes += [r * hidden, r]
         offs, tot = [], 0
         for n_ in sizes:
             offs.append(tot)
             tot += (n_ + 63) // 64 * 64
         gbuf = torch.empty(tot, dtype=torch.float32, device=bank.device)
-        gw1, gb1, gw2, gb2, gwc, gbc = (gbuf[o:o + n_] for o, n_ in zip(offs, sizes))
-        base, gp = buf.data_ptr(), gbuf.data_ptr()
-        _lib.check(lib.repre_replay_head_backward(bank.data_ptr(), K, fin, w2.data_ptr(), wc.data_ptr(), hidden, C_, labels.data_ptr(),
+        gp, base = gbuf.data_ptr(), buf.data_ptr()
+        wp, bp, rp = (C.c_void_p * nh)(*[w.data_ptr() for w in hw]), (C.c_void_p * nh)(*[b.data_ptr() for b in hb]), (C.c_int * nh)(*rows)
+        gwp = (C.c_void_p * nh)(*[gp + 4 * offs[4 + 2 * h] for h in range(nh)])
+        gbp = (C.c_void_p * nh)(*[gp + 4 * offs[5 + 2 * h] for h in range(nh)])
+        _lib.check(lib.repre_replay_head_backward(bank.data_ptr(), K, fin, w2.data_ptr(), wp, bp, rp, nh, hidden, C_, labels.data_ptr(),
                                                   base + 4 * ws_f, base + 4 * (ws_f + n_h), base + 4 * (ws_f + 2 * n_h), go.data_ptr(),
-                                                  gp + 4 * offs[0], gp + 4 * offs[1], gp + 4 * offs[2], gp + 4 * offs[3], gp + 4 * offs[4], gp + 4 * offs[5],
+                                                  gp + 4 * offs[0], gp + 4 * offs[1], gp + 4 * offs[2], gp + 4 * offs[3], gwp, gbp,
                                                   base, ws_f * 4, _stream()), "repre_replay_head_backward")
-        return (None, None, gw1.view(hidden, fin), gb1, gw2.view(hidden, hidden), gb2, gwc.view(C_, hidden), gbc)
+        pieces = [gbuf[o:o + n_] for o, n_ in zip(offs, sizes)]
+        grads = [pieces[0].view(hidden, fin), pieces[1], pieces[2].view(hidden, hidden), pieces[3]]
+        for h, r in enumerate(rows):
+            grads += [pieces[4 + 2 * h].view(r, hidden), pieces[5 + 2 * h]]
+        return (None, None, *grads)
 
 
-def replay_head_loss(bank: torch.Tensor, labels: torch.Tensor, w1, b1, w2, b2, wc, bc):
+def replay_head_loss(bank: torch.Tensor, labels: torch.Tensor, w1, b1, w2, b2, head_weights, head_biases):
     """The per-step replay pass of standard_roi_replay_head.py:468-501 over the two shared FCs and the kept class rows of
     ``Shared2FCBBoxHeadTask`` (convfc_bbox_head_task.py:235-276), fused: ``(loss, scores)`` with
-    ``scores = relu(relu(bank w1^T + b1) w2^T + b2) wc^T + bc`` and ``loss = F.cross_entropy(scores.softmax(-1), labels)``.
-    The bank is a constant (no gradient); gradients flow to the six weight / bias tensors.  fp32, GPU only."""
-    args = [t.float().contiguous() for t in (w1, b1, w2, b2, wc, bc)]
-    return _ReplayHeadLoss.apply(bank.detach().float().contiguous(), labels.contiguous(), *args)
+    ``scores = relu(relu(bank w1^T + b1) w2^T + b2) wc^T + bc`` and ``loss = F.cross_entropy(scores.softmax(-1), labels)``, where
+    ``wc`` / ``bc`` are the rows of ``head_weights`` / ``head_biases`` (the per-task fc_cls heads seen so far, then the background
+    head) read in place.  The bank is a constant (no gradient); gradients flow to every weight / bias.  fp32, GPU only."""
+    flat = []
+    for w, b in zip(head_weights, head_biases):
+        flat += [w.float().contiguous(), b.float().contiguous()]
+    return _ReplayHeadLoss.apply(bank.detach().float().contiguous(), labels.contiguous(), w1.float().contiguous(), b1.float().contiguous(),
+                                 w2.float().contiguous(), b2.float().contiguous(), *flat)
 
 
 def pseudo_label_filter(boxes: torch.Tensor, scores: torch.Tensor, gt_boxes: torch.Tensor, rpn_thresh: float,

@@ -91,7 +91,7 @@ class PrototypeReplay:
     fused_replay = True
 
     def _fused_replay_operands(self):
-        """(w1, b1, w2, b2, wc, bc) when ``bbox_head`` is a two-shared-FC task head whose kept class columns are whole Linear heads
+        """(w1, b1, w2, b2, [head weights], [head biases]) when ``bbox_head`` is a two-shared-FC task head whose kept class columns are whole Linear heads
         (the ``Shared2FCBBoxHeadTask`` of every reference config), else None."""
         h = self.bbox_head
         if getattr(self, "with_shared_head", False) or not hasattr(h, "shared_fcs") or not hasattr(h, "fc_cls"):
@@ -108,16 +108,18 @@ class PrototypeReplay:
         fc1, fc2 = h.shared_fcs
         if any(m.bias is None for m in (fc1, fc2, *live)):
             return None
-        return (fc1.weight, fc1.bias, fc2.weight, fc2.bias, torch.cat([m.weight for m in live], 0), torch.cat([m.bias for m in live], 0))
+        if len(live) > 16:
+            return None
+        return (fc1.weight, fc1.bias, fc2.weight, fc2.bias, [m.weight for m in live], [m.bias for m in live])
 
     def replay_loss_fused(self, bbox_feats):
-        """``replay_loss`` for the loss alone, fused (6 + 6 launches instead of ~40): returns ``dict(replay_loss_cls=...)`` or None
+        """``replay_loss`` for the loss alone, fused (6 + 5 launches instead of ~40): returns ``dict(replay_loss_cls=...)`` or None
         when the head does not have the shape the fused path covers."""
         ops_ = self._fused_replay_operands() if self.fused_replay else None
         if ops_ is None or not bbox_feats.is_cuda:
             return None
         feats = bbox_feats.reshape(bbox_feats.shape[0], -1)
-        if feats.shape[0] > 512 or ops_[4].shape[0] > 256 or feats.shape[1] != ops_[0].shape[1]:
+        if feats.shape[0] > 512 or sum(w.shape[0] for w in ops_[4]) > 256 or feats.shape[1] != ops_[0].shape[1]:
             return None
         loss, _scores = ops.replay_head_loss(feats, self.tmp_label.to(feats.device), *ops_)
         return dict(replay_loss_cls=loss)

@@ -12,5 +12,5 @@ import bench  # noqa: E402
 
 dev = torch.device("cuda:0")
 depth = int(sys.argv[1]) if len(sys.argv) > 1 else 50
-ms, ms4, ms1, flops, n, st = bench._covariance_forward_ms(dev, depth)
+ms, ms4, ms1, flops, n, st = bench._covariance_forward_ms(dev, depth, only_grouped=os.environ.get("COV_ONLY_GROUPED") == "1")
 print(f"R-{depth}: grouped {ms:.3f} ms, hook-time 4 streams {ms4:.3f} ms, 1 stream {ms1:.3f} ms per hooked forward, {n} convs, {st}")
