@@ -432,7 +432,7 @@ PEAK_16BIT_MATRIX_TFLOPS = 2500.0   # dense fp16 / bf16 MFMA peak (MI355X_MICROA
 
 
 def _pmc_file():
-    for name in ("r02/traffic.json", "r01_traffic.json"):
+    for name in ("r03/traffic.json", "r02/traffic.json", "r01_traffic.json"):
         f = os.path.join(ROOT, "profiles", name)
         if os.path.exists(f):
             return f

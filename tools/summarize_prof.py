@@ -92,6 +92,18 @@ for k in agg:
             busy = mean(agg[k]["SQ_VALU_MFMA_BUSY_CYCLES"]) / (1024 * mean(agg[k]["GRBM_GUI_ACTIVE"]) / 8)
             traffic["mfma_busy_fraction" if key == "nsgp_project_kernel" else key + "_mfma_busy_fraction"] = busy
             traffic["mfma_busy_note"] = "SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x GRBM_GUI_ACTIVE / 8)"
+# every kernel of this library that both byte counters saw: HBM bytes per launch (same correction) and, where available, MFMA-busy
+per_kernel = {}
+for k in sorted(agg):
+    rec = {}
+    if "FETCH_SIZE" in agg[k] and "WRITE_SIZE" in agg[k]:
+        rec["hbm_bytes_per_launch"] = mean(agg[k]["FETCH_SIZE"]) * 1024 * 2 + mean(agg[k]["WRITE_SIZE"]) * 1024
+    if "SQ_VALU_MFMA_BUSY_CYCLES" in agg[k] and "GRBM_GUI_ACTIVE" in agg[k] and mean(agg[k]["GRBM_GUI_ACTIVE"]) > 0:
+        rec["mfma_busy_fraction"] = mean(agg[k]["SQ_VALU_MFMA_BUSY_CYCLES"]) / (1024 * mean(agg[k]["GRBM_GUI_ACTIVE"]) / 8)
+    if rec:
+        per_kernel[k] = rec
+if per_kernel:
+    traffic["per_kernel"] = per_kernel
 if len(traffic) > 1:
     traffic["kernel"] = "nsgp_project_v2_kernel<0> (dense path), nsgp_update_lr_kernel<0> / nsgp_lr_apply_kernel<0> / nsgp_update_kernel<0> (default path)"
     json.dump(traffic, open(os.path.join(dst, "traffic.json"), "w"), indent=1)
