@@ -1323,10 +1323,15 @@ extern "C" int nsgp_plan_profile_end(nsgp_plan_t* P, int* n_steps, float* update
         hipEvent_t* e = &P->prof_ev[(size_t)P->prof_per_step * i];
         NSGP_HIP(hipEventSynchronize(e[P->prof_per_step - 1]));
         float ms = 0;
-        NSGP_HIP(hipEventElapsedTime(&ms, e[0], e[1]));
-        det[0] += ms;
-        NSGP_HIP(hipEventElapsedTime(&ms, e[1], e[2]));
-        det[2] += ms;
+        // an interval without a launch measures only the event records themselves (~5 us each): not counted
+        if (P->n_chunks > 0) {
+            NSGP_HIP(hipEventElapsedTime(&ms, e[0], e[1]));
+            det[0] += ms;
+        }
+        if (P->n_tiles_v2 + P->n_tiles_fast + P->n_tiles_generic > 0) {
+            NSGP_HIP(hipEventElapsedTime(&ms, e[1], e[2]));
+            det[2] += ms;
+        }
         for (int g = 0; g < G; ++g) {
             hipEvent_t* ge = e + 2 + 3 * g;
             NSGP_HIP(hipEventElapsedTime(&ms, ge[0], ge[1]));

@@ -289,6 +289,10 @@ class NSCLOptimizerBase(Optimizer):
             # to the next layer's projector) and compare identity + version
             self._basis[name] = dict(U_rm=U_rm, U_kq=U_kq, rank=rank, norm=norm, c=None, P=P, P_version=P._version)
         else:
+            if self.low_rank:        # the default form does not apply: say so (the dense GEMM costs ~3 x the step time of such a layer)
+                why = ("no direction removed" if rank <= 0 else f"{rank} removed directions > {LOW_RANK_MAX}" if rank > LOW_RANK_MAX
+                       else f"D = {D} is not a multiple of 32")
+                logger.info("%s: projector applied as a dense GEMM, not in the low-rank form (%s)", name, why)
             P, norm = ops.build_projector(V, rank, normalise, return_norm=True)
             self._basis.pop(name, None)
         self.transforms[name] = P.detach_()
@@ -555,7 +559,6 @@ class NSCLOptimizerBase(Optimizer):
                     raise AttributeError(f"{n}: 'NoneType' object has no attribute 'data' (parameter has no grad)")
                 grads[i] = g.data_ptr()
                 t = st["step"] + 1
-                st["step"] = t
                 if step_of.setdefault(gi, t) != t:
                     raise RuntimeError("parameters of one param group carry different step counts")
             hyper = plan["hyper"]
@@ -563,4 +566,6 @@ class NSCLOptimizerBase(Optimizer):
                 self._fill_hyper(hyper[k], self.param_groups[gi], step_of[gi])
                 hyper[k].write_grad = mutate
             _lib.check(lib.nsgp_plan_step(plan["handle"], grads, hyper, len(plan["groups"]), stream), "nsgp_plan_step")
+            for _gi, _n, _p, st in plan["entries"]:        # the launches are queued: only now do the step counters advance
+                st["step"] += 1
         return loss

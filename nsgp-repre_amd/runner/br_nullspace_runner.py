@@ -247,6 +247,14 @@ else:
             ``step_fn`` may call ``runner.save_checkpoint(model, 'best_....pth')``; if no file of this task carries
             ``ckpt_keywords`` when the loop ends, the final weights are saved under that keyword."""
             ori = NS.unwrap(self.model)
+            # the batches are walked up to three times (training loop, importance pass, covariance pass / RoI dump): a one-shot iterable
+            # would leave the later passes empty and the hand-off files silently all-zero
+            if not hasattr(batches, "__len__"):
+                batches = list(batches)
+            if cov_batches is not None and not hasattr(cov_batches, "__len__"):
+                cov_batches = list(cov_batches)
+            if len(cov_batches if cov_batches is not None else batches) == 0:
+                raise ValueError("BRNullSpaceRunner.train: no batches for the importance / covariance passes")
             NS.guard_conv_weights(ori)           # stock MIOpen 1x1 backward-data over-read (see the guard); again after loads / teacher copy
             self.set_pseudo_label_thresholds(self.model)                                              # runner:439-441
             if self.task_id != 1:
