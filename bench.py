@@ -297,9 +297,10 @@ def repre_step(N, dev, K, split, reps=30):
             torch.cuda.synchronize()
             ts.append(e0.elapsed_time(e1))
         return sorted(ts)[len(ts) // 2]
-    def steady(fused, amp, n=100):
-        """n passes back to back (no synchronisation in between): HIP events around the run and the host's own issue time"""
-        for _ in range(10):
+    def steady(fused, amp, n=200):
+        """n passes back to back (no synchronisation in between): HIP events around the run and the host's own issue time.  (Short bursts
+        measure the clock ramp: 20 passes after 5 warm-ups read 0.33 ms on a box where 200 after 20 read 0.20.)"""
+        for _ in range(20 if n >= 100 else 5):
             one(fused, amp)
         torch.cuda.synchronize()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -322,7 +323,7 @@ def repre_step(N, dev, K, split, reps=30):
     rp.fused_replay = True
     return {"K": K, "task_split": list(split), "kept_class_columns": C_, "repre_step_ms": stream_ms, "host_issue_ms": host_ms,
             "isolated_pass_ms": iso_ms, "isolated_forward_only_ms": fused_fwd_ms, "module_path_fp32_ms": module_ms, "module_path_bf16_autocast_ms": bf16_ms,
-            "timing": "HIP events around 100 passes back to back after 10 warm-ups (head.zero_grad + forward + backward each); isolated = median of 30 "
+            "timing": "HIP events around 200 passes back to back after 20 warm-ups (head.zero_grad + forward + backward each); isolated = median of 30 "
                       "passes with a synchronisation before each; module paths: the same steady-state protocol",
             "launches": "forward: skinny split-K GEMM + slab reduce (x2), class scores + row CE terms, mean = 6; backward: CE, dZ2 (+ class-head gradients), "
                         "skinny GEMM, dZ1, grouped weight-gradient GEMM = 5 (csrc/replay_head.hip)",
