@@ -191,7 +191,9 @@ class CovGroupPlan:
         self.device = device
         self._ws = None
 
-    def run(self, xs, covs):
+    def run(self, xs, covs, workspace=None):
+        """``workspace``: an optional uint8 GPU tensor of at least ``workspace_bytes`` (callers that keep several plans alive -- one
+        per input geometry -- share one); by default the plan allocates and keeps its own."""
         if self._handle is None:
             raise RuntimeError("CovGroupPlan is closed")
         lib = _lib.load_library()
@@ -214,9 +216,14 @@ class CovGroupPlan:
                 raise ValueError("the covariances of one grouped run must be distinct buffers")
             seen.add(c.data_ptr())
             cp[i] = _dev(c, "cov").value
-        if self._ws is None or self._ws.numel() < self.workspace_bytes:
-            self._ws = torch.empty(max(self.workspace_bytes, 16), dtype=torch.uint8, device=self.device)
-        _lib.check(lib.nsgp_cov_plan_run(self._handle, xp, cp, acc, C.c_void_p(self._ws.data_ptr()), self._ws.numel(), _stream()), "nsgp_cov_plan_run")
+        ws = workspace
+        if ws is None:
+            if self._ws is None or self._ws.numel() < self.workspace_bytes:
+                self._ws = torch.empty(max(self.workspace_bytes, 16), dtype=torch.uint8, device=self.device)
+            ws = self._ws
+        elif not ws.is_cuda or ws.dtype != torch.uint8 or ws.numel() < self.workspace_bytes:
+            raise ValueError(f"workspace must be a uint8 GPU tensor of at least {self.workspace_bytes} bytes")
+        _lib.check(lib.nsgp_cov_plan_run(self._handle, xp, cp, acc, C.c_void_p(ws.data_ptr()), ws.numel(), _stream()), "nsgp_cov_plan_run")
         for i, (c, ok) in enumerate(zip(covs, self.routes)):
             if ok and c is not None:
                 _touched(c)

@@ -566,9 +566,9 @@ class NSCLOptimizerBase(Optimizer):
         mutate = int(self.mutate_grad)
         for plan in self._plans:
             glist = [p.grad for p in plan["params"]]
-            if None in glist:
-                n = plan["names"][glist.index(None)]
-                raise AttributeError(f"{n}: 'NoneType' object has no attribute 'data' (parameter has no grad)")
+            for i, g in enumerate(glist):      # identity, not `None in glist`: `in` falls back to Tensor.__eq__(None), an op per tensor
+                if g is None:
+                    raise AttributeError(f"{plan['names'][i]}: 'NoneType' object has no attribute 'data' (parameter has no grad)")
             plan["grads"][:] = [g.data_ptr() for g in glist]
             steps = [st["step"] for st in plan["states"]]
             hyper = plan["hyper"]

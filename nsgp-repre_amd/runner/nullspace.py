@@ -137,6 +137,9 @@ class CovarianceCollector:
         self.grouped = grouped
         self._pending = []
         self._plans = {}
+        self._group_ws = None
+
+    MAX_PLANS = 8      # grouped plans kept alive (one per input geometry)
 
     def hooked_modules(self):
         # every module that has a `.weight` and is not ignored (runner:723-724); only Conv2d and
@@ -168,6 +171,7 @@ class CovarianceCollector:
         for plan in self._plans.values():
             plan.close()
         self._plans = {}
+        self._group_ws = None
 
     @torch.no_grad()
     def flush(self):
@@ -185,10 +189,18 @@ class CovarianceCollector:
             seen.add(n)
         geoms = tuple((x.shape[0], x.shape[1], x.shape[2], x.shape[3], k, s, p) for _n, x, k, s, p in first)
         dev = first[0][1].device
-        plan = self._plans.get((geoms, dev))
+        # one plan per input geometry (real loaders pad to many sizes): the most recent MAX_PLANS are kept, all of them share ONE
+        # workspace (the materialised operands: ~3 GB for R-50-FPN at 800 x 1344) that only ever grows
+        plan = self._plans.pop((geoms, dev), None)
         if plan is None:
-            plan = self._plans[(geoms, dev)] = ops.CovGroupPlan(geoms, dev)
-        covs = plan.run([x for _n, x, _k, _s, _p in first], [self.fea_in.get(n) for n, *_ in first])
+            plan = ops.CovGroupPlan(geoms, dev)
+            while len(self._plans) >= self.MAX_PLANS:
+                self._plans.pop(next(iter(self._plans))).close()
+        self._plans[(geoms, dev)] = plan                       # (re-)inserted last: dicts keep insertion order -> LRU
+        if self._group_ws is None or self._group_ws.numel() < plan.workspace_bytes or self._group_ws.device != dev:
+            self._group_ws = None                                # release before growing
+            self._group_ws = torch.empty(max(plan.workspace_bytes, 16), dtype=torch.uint8, device=dev)
+        covs = plan.run([x for _n, x, _k, _s, _p in first], [self.fea_in.get(n) for n, *_ in first], workspace=self._group_ws)
         for (n, x, k, s, p), c, ok in zip(first, covs, plan.routes):
             if ok:
                 self.fea_in[n] = c

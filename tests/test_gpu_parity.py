@@ -396,6 +396,22 @@ def test_grouped_covariance_pass_vs_single_layer_path_and_oracle(N, dev):
     assert sorted(res[True]) == sorted(res[False]) == ["0.weight", "2.weight", "4.weight"]
     for k in res[True]:
         assert _rel(res[True][k], res[False][k]) <= REL, k
+    # inputs of changing size (real loaders pad to many shapes): one plan per geometry, at most MAX_PLANS alive, ONE shared workspace
+    col = N.runner.CovarianceCollector(net, [], grouped=True).register()
+    col.MAX_PLANS = 2
+    want = None
+    with torch.no_grad():
+        for hw in ((24, 32), (16, 40), (24, 32), (32, 24), (16, 40)):
+            xi = torch.randn(1, 64, *hw, generator=g).abs().to(dev)
+            net(xi)
+            col.flush()
+            assert len(col._plans) <= 2 and col._group_ws is not None
+            ref = O.cov_conv2d(xi.cpu(), (3, 3), (1, 1), (1, 1))
+            want = ref if want is None else want + ref
+    col.remove()
+    assert _rel(col.fea_in["0.weight"], want) <= REL
+    col.close()
+    assert col._plans == {} and col._group_ws is None
 
 
 @pytest.mark.parametrize("mode", [0, 2, 3, 4])
