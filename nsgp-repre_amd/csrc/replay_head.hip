@@ -10,19 +10,23 @@
 //
 // and the weight gradients  dW1 = dZ1^T X,  dW2 = dZ2^T H1,  dWc = dS^T H2  (+ bias gradients).  The reference runs this through
 // autograd: ~15 library GEMM / elementwise launches forward and ~25 backward for K = 150 rows, i.e. pure launch overhead around
-// one 51 MB weight pass each way.  Everything here is exact fp32 on v_mfma_f32_32x32x2_f32 (the bank pass is kept at the
-// reference's fp32 width; bf16 autocast in the reference would only lower it).
+// one 51 MB weight pass each way (0.69 ms per step in round 2, host-bound).  Here: 6 launches forward, 5 backward, everything exact
+// fp32 on v_mfma_f32_32x32x2_f32 in a fixed order (the bank pass is kept at the reference's fp32 width; bf16 autocast in the
+// reference would only lower it).
 //
 // Kernels
 //   rh_skinny_kernel   C[M x N] = A[M x K] B^T (or A B) for M <= 160 rows per workgroup: a workgroup owns ALL (<= 5) 32-row blocks of
-//                      the skinny operand x 128 columns (one 32-column block per wave, 5 accumulators) x one K range; the K ranges
-//                      of one column tile write slabs that the next launch sums in range order (deterministic).  M = 150 wastes 6 %
-//                      of the matrix work (a 128 x 128 tile: 41 %).  K ranges are dealt to XCDs (blockIdx % 8) so that the skinny
-//                      operand's K slice is fetched into one L2.
+//                      the skinny operand x 128 columns (one 32-column block per wave, 5 accumulators) x one K range (>= 4 k32 steps);
+//                      the K ranges of one column tile write slabs that the next launch sums in range order (deterministic).  M = 150
+//                      wastes 6 % of the matrix work (a 128 x 128 tile: 41 %).  K ranges are dealt to XCDs (blockIdx % 8) so that the
+//                      skinny operand's K slice is fetched into one L2.
 //   rh_reduce_kernel   H = relu(sum of slabs + bias).
-//   rh_scores_kernel   S = H2 Wc^T + bc, one wave per row.
+//   rh_scores_kernel   S = H2 Wc^T + bc, one ROW per workgroup (thread = (class, k slice)), then the row's double-softmax CE term;
+//                      the class rows are read in place through a table of the per-task heads (RhHeads), no stacked copy.
+//   rh_mean_kernel     loss = ordered mean of the row terms.
 //   rh_dz_kernel       dZ = (upstream) * (H > 0) with its transposed, zero-padded copy (the A operand of the weight-gradient GEMM)
-//                      and the bias gradient (ordered column sums); upstream = the slab sum (dZ2 W2) or dS Wc.
+//                      and the bias gradient (ordered column sums); upstream = the slab sum (dZ2 W2) or dS Wc; in the second mode also
+//                      the class heads' gradients dWc = dS^T H2 (written straight into the per-head buffers) and dbc.
 //   rh_tn_kernel       dW[No x Ni] = dZ^T[No x Mp] X[M x Ni] on the 128 x 128 fp32 tile of gemm_core.hpp, grouped over jobs.
 #include <algorithm>
 #include <cstdlib>
