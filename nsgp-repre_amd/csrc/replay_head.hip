@@ -29,7 +29,6 @@
 //                      the class heads' gradients dWc = dS^T H2 (written straight into the per-head buffers) and dbc.
 //   rh_tn_kernel       dW[No x Ni] = dZ^T[No x Mp] X[M x Ni] on the 128 x 128 fp32 tile of gemm_core.hpp, grouped over jobs.
 #include <algorithm>
-#include <cstdlib>
 
 #include "common.hpp"
 #include "gemm_core.hpp"
@@ -40,7 +39,7 @@ namespace nsgp {
 constexpr int RH_MAX_MB = 5;          // 32-row blocks per workgroup of the skinny kernel
 constexpr int RH_MAX_ROWS = 512;      // K <= 10 prototypes x 40 old classes = 400 (COCO 40+40)
 constexpr int RH_MAX_COLS = 256;      // the CE kernels' limit
-constexpr int RH_TARGET_WGS = 512;    // two workgroups per CU
+constexpr int RH_TARGET_WGS = 256;    // one workgroup per CU (measured on the first FC at K = 150: 51 us; 512: 54-57, 1024: 60)
 
 template <int MB> constexpr int rh_aplane() { return MB * 32 * 4 + 4; }
 template <int MB> constexpr int rh_smem_floats() { return 2 * 8 * rh_aplane<MB>() + 2 * ROW_IMG; }
@@ -512,8 +511,7 @@ static RhPlan rh_plan(int M, int N, int K) {
     p.Mpad = p.mchunks * p.MB * 32;
     p.ntn = (N + 127) / 128;
     const int nk = (K + 31) / 32;
-    static const int target = [] { const char* e = getenv("NSGP_RH_WGS"); const int v = e ? atoi(e) : 0; return v > 0 ? v : RH_TARGET_WGS; }();   // study knob
-    int S = std::max(1, std::min(std::max(1, nk / 4), target / std::max(1, p.ntn * p.mchunks)));     // >= 4 k-steps per range
+    int S = std::max(1, std::min(std::max(1, nk / 4), RH_TARGET_WGS / std::max(1, p.ntn * p.mchunks)));     // >= 4 k-steps per range
     p.per = (nk + S - 1) / S;
     p.S = (nk + p.per - 1) / p.per;
     p.grid = 8 * p.ntn * p.mchunks * ((p.S + 7) / 8);

@@ -34,4 +34,4 @@ for _ in range(20):
     rp.add_replay_loss({})["replay_loss_cls"].backward()
 e1.record()
 torch.cuda.synchronize()
-print(f"K = {K}: {e0.elapsed_time(e1) / 20:.4f} ms per fused pass, back to back (NSGP_RH_WGS = {os.environ.get('NSGP_RH_WGS', 'default')})")
+print(f"K = {K}: {e0.elapsed_time(e1) / 20:.4f} ms per fused pass, back to back (steady state needs more passes: see bench.py)")
