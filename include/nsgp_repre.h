@@ -205,8 +205,8 @@ int nsgp_cov_accumulate_conv2d(const float* x, int batch, int cin, int h, int w,
                                int sh, int sw, int ph, int pw, float* cov, int accumulate,
                                void* workspace, size_t workspace_bytes, void* stream);
 /* Linear branch (runner:901-902): X = mean(x, 0, keepdim) with x [B x F] -> C (+)= X^T X (rank 1). */
-/* Grouped covariance pass: every eligible hooked convolution of ONE forward in five launches (mean / amax / operand split / one
- * tile table over all layers, longest K first, no split-K and no reduce: each tile writes its block of C and the mirror).  Replaces
+/* Grouped covariance pass: every eligible hooked convolution of ONE forward in a handful of launches (mean / amax / operand split /
+ * one tile table over all layers, longest K first, no split-K: each tile writes its block of C and the mirror).  Replaces
  * the per-hook launches of compute_cov + update_cov, nsrunner_roi_replay.py:876-934, for a whole forward of cal_fea_in (:705-763).
  * A plan is built once per model geometry; nsgp_cov_plan_routes says which layers the grouped launches take (1) and which stay on
  * nsgp_cov_accumulate_conv2d (0: D = cin*kh*kw not a multiple of 64, or fewer than 32 output positions).  nsgp_cov_plan_run borrows
@@ -224,6 +224,16 @@ size_t nsgp_cov_plan_workspace_bytes(const nsgp_cov_plan_t* plan);
 int nsgp_cov_plan_routes(const nsgp_cov_plan_t* plan, int* routes, int n);
 /* n_grouped layers, tiles of the SYRK launch, and sum over the grouped layers of L*D*(D+128) = the FLOPs of the upper triangles (blocks on the diagonal counted whole) */
 int nsgp_cov_plan_stats(const nsgp_cov_plan_t* plan, int* n_grouped, int* n_tiles, double* upper_flops);
+/* Correlation form.  A 3x3 / stride 1 / padding 1 convolution's covariance is 81 C x C blocks that depend on their two kernel taps
+ * almost only through the taps' difference: summed over one ring of positions more than the convolution has, block ((ky1,kx1),(ky2,kx2))
+ * IS the shifted correlation R[ky2-ky1, kx2-kx1] = sum_q X[c1][q] X[c2][q + shift] -- 13 distinct C x C products instead of 40.5 --
+ * and the ring's own covariance (2(H+W)+4 positions, four strip layers) is subtracted afterwards.  The plan takes this form per layer
+ * where it saves tile-steps (the large feature maps; same fp16-split tile, same per-layer scale, sums cut into ordered ranges, C
+ * bit-symmetric and bitwise reproducible as before).  nsgp_cov_plan_forms: layers in that form and the k32 steps of 256 x 128 tiles
+ * the plan's SYRK launches execute; nsgp_cov_set_corr_mode (process-wide, read at plan creation; returns the previous mode):
+ * 0 never, 1 by the rule (default), 2 wherever it applies. */
+int nsgp_cov_plan_forms(const nsgp_cov_plan_t* plan, int* n_correlation_form, double* tile_steps);
+int nsgp_cov_set_corr_mode(int mode);
 int nsgp_cov_plan_run(nsgp_cov_plan_t* plan, const float* const* x, float* const* cov, const int* accumulate, void* workspace,
                       size_t workspace_bytes, void* stream);
 int nsgp_cov_accumulate_linear(const float* x, int batch, int features, float* cov, int accumulate,

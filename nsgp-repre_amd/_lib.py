@@ -59,6 +59,8 @@ SIGNATURES = {
     "nsgp_cov_plan_workspace_bytes": (C.c_size_t, [C.c_void_p]),
     "nsgp_cov_plan_routes": (C.c_int, [C.c_void_p, C.POINTER(C.c_int), C.c_int]),
     "nsgp_cov_plan_stats": (C.c_int, [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_double)]),
+    "nsgp_cov_plan_forms": (C.c_int, [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_double)]),
+    "nsgp_cov_set_corr_mode": (C.c_int, [C.c_int]),
     "nsgp_cov_plan_run": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_int), C.c_void_p, C.c_size_t, C.c_void_p]),
     "nsgp_cov_accumulate_linear": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p]),
     "nsgp_projector_scratch_bytes": (C.c_size_t, [C.c_int]),

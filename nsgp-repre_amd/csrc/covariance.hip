@@ -686,33 +686,63 @@ extern "C" int nsgp_cov_accumulate_conv2d(const float* x, int batch, int cin, in
 
 namespace nsgp {
 
-// ---- grouped pass: every eligible hooked layer of ONE forward in five launches ------------------------------------------------
+// ---- grouped pass: every eligible hooked layer of ONE forward in a handful of launches ------------------------------------------
 // One hooked forward of R-50-FPN is 61 accumulations; issued layer by layer they are 4-5 launches each, most of them far too small
 // to fill 256 CUs, every wide layer needs split-K slabs + a reduce launch to fill the chip on its own, and each pays a memset +
 // amax launch for its fp16 scale (round 2: 7.4 ms of back-to-back GPU time, 5.6 ms over four streams).  Here the hooks only stash
 // their inputs; at the end of the forward ONE plan run does, for all layers with D % 64 == 0 together:
 //   nsgp_cov_group_mean_kernel   batch mean + zero border, for the layers that need it (B > 1 or padding);
 //   nsgp_cov_group_amax_kernel   largest |activation| per layer -> its power-of-two fp16 scale;
-//   nsgp_cov_group_split_kernel  X^T of every layer as the pre-tiled, pre-scaled two-term fp16 operand (gemm_f16x2_v2.hpp);
+//   nsgp_cov_group_split_kernel  the pre-tiled, pre-scaled two-term fp16 operand of every layer (gemm_f16x2_v2.hpp);
 //   nsgp_cov_group_syrk_kernel   ONE tile table over all layers, longest K first (in-order dispatch = LPT list scheduling on the
-//                                256 one-workgroup CUs).  With ~2,500 tiles from 60 layers in one launch the chip is full without
-//                                split-K: a tile contracts its whole L, and its epilogue unscales and writes (or accumulates into) C
-//                                directly -- upper-triangle blocks plus their mirrors, diagonal blocks symmetrised through LDS -- so
-//                                there are no slabs and no reduce launch.  Every element of C is written by exactly one tile in a
-//                                fixed k order: bitwise reproducible.
+//                                256 one-workgroup CUs).  With thousands of tiles from 60 layers in one launch the chip is full
+//                                without split-K: a tile contracts its whole L, and its epilogue unscales and writes (or accumulates
+//                                into) C directly -- upper-triangle blocks plus their mirrors, diagonal blocks symmetrised through
+//                                LDS.  Every element of C is written by exactly one tile in a fixed k order: bitwise reproducible.
 // Layers the tile cannot take (D % 64 != 0: the 7x7 stem; Linear) stay on the single-layer entry points.
+//
+// CORRELATION FORM of the 3x3 / stride 1 / padding 1 convolutions (where almost all of the work is: the two 3x3s that see the
+// stride-4 FPN level are 70 % of an R-50-FPN forward's tile-steps).  Their covariance is 81 blocks of C x C,
+//     Cov[(c1,ky1,kx1), (c2,ky2,kx2)] = sum over output positions (y,x) of X[c1][y+ky1-1][x+kx1-1] X[c2][y+ky2-1][x+kx2-1],
+// and a block depends on its two kernel taps almost only through their DIFFERENCE (dy, dx) = (ky2-ky1, kx2-kx1): summed over the
+// EXTENDED position set y in [-1, H], x in [-1, W] (one ring more than the convolution has), every tap sweeps the whole image and
+//     Cov_ext[(c1,ky1,kx1), (c2,ky2,kx2)] = R[dy,dx][c1,c2] := sum over all pixels q of X[c1][q] X[c2][q + (dy,dx)]      (zero outside).
+// So  Cov = Cov_ext - Cov_ring:  25 shifted C x C correlations (13 up to transposition: R[-d] = R[d]^T) instead of 81 blocks
+// (40.5 up to symmetry), minus the covariance of the ring's 2(H + W) + 4 positions.  In memory a shift is an OFFSET: with the image
+// laid out flat at a row pitch Wq >= W + 4 (two zero rows above and below, zero columns in between), q + (dy,dx) = q + dy Wq + dx.
+//   operand:   five copies of the flat image shifted by dx = -2..2, rows (copy j, channel c), pre-tiled as always:  5 C x (H+4) Wq
+//              instead of 9 C x H W  (the LDS-DMA loader needs 16-byte-aligned pieces: dx cannot be an address offset, dy Wq can);
+//   R tiles:   A = the dx = 0 copy (C rows), B = all copies read dy Wq / 32 k-steps further on -- the same tile function, a byte
+//              offset on B.  dy = 0 needs dx >= 0 only.  13 C^2 instead of 40.5 C^2 products per position: ~2.5-2.8 x fewer
+//              tile-steps net of the row-pitch padding.  Contractions are cut into ranges of <= CG_CORR_MAX_STEPS, raw sums to slabs;
+//   nsgp_cov_corr_reduce_kernel    R[dy][c1][(dx, c2)] = ordered sum of the range slabs;
+//   nsgp_cov_corr_assemble_kernel  C[d1][d2] (=|+=) unscale * R at the canonical orientation of the pair (dy > 0, or dy = 0 and dx > 0,
+//              or the same tap and c1 <= c2): (d1,d2) and (d2,d1) read the same number, C stays bit-symmetric;
+//   ring:      ONE more im2col layer per parent whose columns are the ring's positions (rows y = -1, H and columns x = -1, W), through the
+//              ordinary tiles in a second, small SYRK launch whose epilogue SUBTRACTS.
+// Chosen per layer by tile-step count (plan creation; nsgp_cov_set_corr_mode forces it on or off for tests and studies).
 struct CovGroupLayer {
-    ConvGeom g;
-    int cin, H, W, ph, pw, batch;
-    int Dp, Lp;
-    int needs_mean;          // 0: the input is its own batch mean (B == 1, no padding)
-    long xm_off, xt_off;     // byte offsets into the workspace
-    long n_img;              // elements of the (padded) mean image
+    ConvGeom g;              // kinds 0 / 2: im2col geometry over the window; kind 1: D = 9 C, L = H W, Hp = H, Wp = W (the raw image)
+    int kind;                // 0 im2col layer; 1 correlation form; 2 the ring of a kind-1 layer
+    int cin, H, W, batch;    // the hooked input [batch x cin x H x W]
+    int oy, ox;              // window origin in image coordinates (window = g.Hp x g.Wp; outside the image: zero)
+    int Dp, Lp;              // operand rows, contraction length (kind 1: pad128(5 Cp) rows, (H + 4) Wq)
+    int needs_mean;          // 0: the input is its own batch mean and needs no border (B == 1 and no padding, or kind 1 with B == 1)
+    int src;                 // slot of x / cov / accumulate / amax in the per-run tables (a ring: its parent's)
+    float sign;              // +1; rings: -1
+    int Wq, Cp;              // kind 1: flat row pitch (a multiple of 32), channels padded to 64
+    long xm_off, xt_off, r_off;   // byte offsets into the workspace (-1: none)
+    long n_img;              // elements of the window image
 };
 struct CovGroupTile {
     int layer, rb0, cb0, mb;
-    int step0, nsteps;       // the k32 steps this workgroup contracts
-    long slab;               // >= 0: index of the 256 x 128 slab this K range writes (long contractions are cut: see CG_MAX_STEPS); -1: direct epilogue
+    int step0, nsteps;       // the k32 steps this workgroup contracts (of the A operand)
+    int bstep;               // the B operand is read this many k-steps further on (correlation tiles: dy Wq / 32)
+    long slab;               // >= 0: index of the 256 x 128 slab this K range writes; -1: direct epilogue
+};
+struct CovCorrUnit {         // one R tile: its S range slabs -> R[dy][ca0 ..][col0 ..]
+    int layer, dy, ca0, mb, col0, S;
+    long slab0;
 };
 
 __device__ __forceinline__ int cov_group_find(const int* __restrict__ prefix, int n, int unit) {
@@ -727,10 +757,11 @@ __device__ __forceinline__ int cov_group_find(const int* __restrict__ prefix, in
 constexpr int CG_CHUNK = 256 * 64;       // elements per workgroup of the mean / amax launches (64 KB of fp32)
 // A tile's contraction is ONE fp32 accumulator chain: over L = 67,200 positions (2,100 steps) its rounding reached 9.7e-6 of a row's
 // maximum against fp64 -- the whole 1e-5 gate (profiles/r03/covariance_true_size.json, first form).  Contractions longer than this many
-// steps are therefore cut into equal K ranges whose slabs the ordered reduce of the single-layer path sums (a blocked summation:
-// 2.5e-6); that concerns the 13 layers of an R-50-FPN that see the stride-4 feature map, everything else writes C directly.
+// steps are therefore cut into equal K ranges whose slabs an ordered reduce sums (a blocked summation: 2.5e-6).
 constexpr int CG_MAX_STEPS = 600;
+constexpr int CG_CORR_MAX_STEPS = 320;   // correlation tiles: few tiles per layer (26 for C = 256), so shorter ranges also balance the launch
 constexpr int CG_SPLIT_OCTETS = 16;      // l-octets per workgroup of the operand-split launch (4 per wave)
+constexpr int CG_ASM_ROWS = 4;           // rows of C per workgroup of the assemble launch
 
 // dyn: [x pointers n][cov pointers n][accumulate flags n]
 __device__ __forceinline__ const float* cg_x(const void* dyn, int i) { return reinterpret_cast<const float* const*>(dyn)[i]; }
@@ -741,9 +772,9 @@ __global__ __launch_bounds__(256) void nsgp_cov_group_mean_kernel(const CovGroup
                                                                   const void* __restrict__ dyn, char* __restrict__ ws) {
     const int li = cov_group_find(prefix, n, blockIdx.x);
     const CovGroupLayer L = layers[li];
-    const float* __restrict__ x = cg_x(dyn, li);
+    const float* __restrict__ x = cg_x(dyn, L.src);
     float* __restrict__ xm = reinterpret_cast<float*>(ws + L.xm_off);
-    const int Hp = L.H + 2 * L.ph, Wp = L.W + 2 * L.pw;
+    const int Hp = L.g.Hp, Wp = L.g.Wp;
     const long base = (long)(blockIdx.x - prefix[li]) * CG_CHUNK, end = min(base + CG_CHUNK, L.n_img);
     const long bs = (long)L.cin * L.H * L.W;
     // one division per thread, then an incremental (row, column) walk in steps of 256 elements
@@ -754,8 +785,9 @@ __global__ __launch_bounds__(256) void nsgp_cov_group_mean_kernel(const CovGroup
     const int qr = 256 / Wp, rr = 256 - qr * Wp;
     for (; idx < end; idx += 256) {
         float v = 0.0f;
-        if (yy >= L.ph && yy < L.ph + L.H && xx >= L.pw && xx < L.pw + L.W) {
-            const long off = ((long)c * L.H + (yy - L.ph)) * L.W + (xx - L.pw);
+        const int iy = yy + L.oy, ix = xx + L.ox;
+        if (iy >= 0 && iy < L.H && ix >= 0 && ix < L.W) {
+            const long off = ((long)c * L.H + iy) * L.W + ix;
             float s = x[off];
             for (int b = 1; b < L.batch; ++b) s += x[off + b * bs];      // torch.mean(x, 0, True): sum over b, then / B
             v = (L.batch > 1) ? s / (float)L.batch : s;
@@ -768,15 +800,15 @@ __global__ __launch_bounds__(256) void nsgp_cov_group_mean_kernel(const CovGroup
     }
 }
 
-__device__ __forceinline__ const float* cg_image(const CovGroupLayer& L, const void* dyn, int li, const char* ws) {
-    return L.needs_mean ? reinterpret_cast<const float*>(ws + L.xm_off) : cg_x(dyn, li);
+__device__ __forceinline__ const float* cg_image(const CovGroupLayer& L, const void* dyn, const char* ws) {
+    return L.needs_mean ? reinterpret_cast<const float*>(ws + L.xm_off) : cg_x(dyn, L.src);
 }
 
 __global__ __launch_bounds__(256) void nsgp_cov_group_amax_kernel(const CovGroupLayer* __restrict__ layers, const int* __restrict__ prefix, int n,
                                                                   const void* __restrict__ dyn, const char* __restrict__ ws, unsigned* __restrict__ amax) {
     const int li = cov_group_find(prefix, n, blockIdx.x);
     const CovGroupLayer L = layers[li];
-    const float* __restrict__ xm = cg_image(L, dyn, li, ws);
+    const float* __restrict__ xm = cg_image(L, dyn, ws);
     const long base = (long)(blockIdx.x - prefix[li]) * CG_CHUNK, end = min(base + CG_CHUNK, L.n_img);
     float am = 0.0f;
     if ((((uintptr_t)xm) & 15u) == 0 && end - base == CG_CHUNK) {
@@ -804,9 +836,73 @@ __global__ __launch_bounds__(256) void nsgp_cov_group_split_kernel(const CovGrou
     const int nob = (L.Lp / 8 + CG_SPLIT_OCTETS - 1) / CG_SPLIT_OCTETS;      // workgroups along l
     const int ob = u % nob, db = u / nob;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const float* __restrict__ xm = cg_image(L, dyn, li, ws);
+    const float* __restrict__ xm = cg_image(L, dyn, ws);
     const int d = db * 64 + lane;
-    const float scale = f2_scale_from_amax_bits(amax[li]);
+    const float scale = f2_scale_from_amax_bits(amax[L.src]);
+    if (L.kind == 1) {
+        // correlation operand: row d = (copy j, channel c) holds the flat zero-bordered image shifted by dx = j - 2:
+        // element q = r Wq + s  <-  X[c][r - 2][s + j - 4]
+        const int j = d / L.Cp, c = d - j * L.Cp;
+        const bool live = j < 5 && c < L.cin;
+        const float* __restrict__ img = xm + (long)c * L.H * L.W;
+#pragma unroll
+        for (int i = 0; i < CG_SPLIT_OCTETS / 4; ++i) {
+            const int o = ob * CG_SPLIT_OCTETS + 4 * i + wave;
+            if (o * 8 >= L.Lp) break;                            // uniform per wave
+            const int q0 = o * 8, r = q0 / L.Wq, s0 = q0 - r * L.Wq;      // Wq % 8 == 0: the octet stays in one row
+            const int iy = r - 2, ix0 = s0 + j - 4;
+            f32x4 v[2];
+            v[0] = f32x4{0, 0, 0, 0};
+            v[1] = f32x4{0, 0, 0, 0};
+            if (live && iy >= 0 && iy < L.H && ix0 + 7 >= 0 && ix0 < L.W) {
+                const float* __restrict__ rowp = img + (long)iy * L.W;
+                if (ix0 >= 0 && ix0 + 7 < L.W) {
+                    const f32x4_u q0v = *(const gf32x4_u*)(rowp + ix0), q1v = *(const gf32x4_u*)(rowp + ix0 + 4);
+                    v[0] = f32x4{q0v[0], q0v[1], q0v[2], q0v[3]};
+                    v[1] = f32x4{q1v[0], q1v[1], q1v[2], q1v[3]};
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        const int ix = ix0 + e;
+                        if (ix >= 0 && ix < L.W) v[e >> 2][e & 3] = as_global(rowp)[ix];
+                    }
+                }
+            }
+            v2_store_pieces(ws + L.xt_off, d, o, L.Lp, v[0], v[1], scale);
+        }
+        return;
+    }
+    if (L.kind == 2) {
+        // ring operand: column l is ring position l -- the rows y = -1 and y = H (x = -1 .. W), then the columns x = -1 and x = W
+        // (y = 0 .. H - 1) -- of the parent's image, row d = (c, ky, kx) reads X[c][y + ky - 1][x + kx - 1] (zero outside)
+        const int c = d / 9, tap = d - 9 * c, ky = tap / 3, kx = tap - 3 * ky;
+        const float* __restrict__ img = xm + (long)c * L.H * L.W;
+        const int w2 = L.W + 2;
+#pragma unroll
+        for (int i = 0; i < CG_SPLIT_OCTETS / 4; ++i) {
+            const int o = ob * CG_SPLIT_OCTETS + 4 * i + wave;
+            if (o * 8 >= L.Lp) break;                            // uniform per wave
+            f32x4 v[2];
+            v[0] = f32x4{0, 0, 0, 0};
+            v[1] = f32x4{0, 0, 0, 0};
+            if (d < L.g.D) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const int l = o * 8 + e;
+                    if (l >= L.g.L) break;
+                    int y, x;
+                    if (l < w2) { y = -1; x = l - 1; }
+                    else if (l < 2 * w2) { y = L.H; x = l - w2 - 1; }
+                    else if (l < 2 * w2 + L.H) { y = l - 2 * w2; x = -1; }
+                    else { y = l - 2 * w2 - L.H; x = L.W; }
+                    const int iy = y + ky - 1, ix = x + kx - 1;
+                    if (iy >= 0 && iy < L.H && ix >= 0 && ix < L.W) v[e >> 2][e & 3] = as_global(img)[(long)iy * L.W + ix];
+                }
+            }
+            v2_store_pieces(ws + L.xt_off, d, o, L.Lp, v[0], v[1], scale);
+        }
+        return;
+    }
     const long rowbase = im2col_rowbase1(L.g, d);
     const float inv_wo = 1.0f / (float)L.g.Wo;
 #pragma unroll
@@ -833,14 +929,15 @@ __global__ __launch_bounds__(V2L_THREADS, 3) void nsgp_cov_group_syrk_kernel(con
     extern __shared__ __attribute__((aligned(16))) char smem_c[];
     const CovGroupTile t = tiles[blockIdx.x];
     const CovGroupLayer L = layers[t.layer];
-    const void* xt = ws + L.xt_off;
+    const char* xt = ws + L.xt_off;
+    const char* xb = xt + (size_t)t.bstep * V2_STEP;             // the same operand, read bstep k-steps further on (0 but for correlation tiles)
     f32x16 acc[2][2];
     zero_acc(acc);
-    if (t.mb == 4) gemm_tile_f16x2_v2l<4>(xt, t.rb0, xt, t.cb0, L.Lp, smem_c, acc, t.step0, t.nsteps);
-    else gemm_tile_f16x2_v2l<2>(xt, t.rb0, xt, t.cb0, L.Lp, smem_c, acc, t.step0, t.nsteps);
+    if (t.mb == 4) gemm_tile_f16x2_v2l<4>(xt, t.rb0, xb, t.cb0, L.Lp, smem_c, acc, t.step0, t.nsteps);
+    else gemm_tile_f16x2_v2l<2>(xt, t.rb0, xb, t.cb0, L.Lp, smem_c, acc, t.step0, t.nsteps);
     // every wave is back (the loaders too) and the ring is free
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    if (t.slab >= 0) {                                           // one K range of a long contraction: raw partial sums to its slab
+    if (t.slab >= 0) {                                           // one K range of a long contraction / of an R tile: raw partial sums to its slab
         if (wave >= 2 * t.mb) return;
         float* smem = reinterpret_cast<float*>(smem_c);
         float* out = slabs + (size_t)t.slab * (256 * 128);
@@ -853,8 +950,8 @@ __global__ __launch_bounds__(V2L_THREADS, 3) void nsgp_cov_group_syrk_kernel(con
     }
     // park the unscaled 256 (128) x 128 block in LDS
     float* T = reinterpret_cast<float*>(smem_c);
-    const float sc = f2_scale_from_amax_bits(amax[t.layer]);
-    const float unscale = (1.0f / sc) * (1.0f / sc);
+    const float sc = f2_scale_from_amax_bits(amax[L.src]);
+    const float unscale = L.sign * ((1.0f / sc) * (1.0f / sc));
     if (wave < 2 * t.mb) {
         const int wm = wave >> 1, wn = wave & 1;
 #pragma unroll
@@ -866,8 +963,8 @@ __global__ __launch_bounds__(V2L_THREADS, 3) void nsgp_cov_group_syrk_kernel(con
                     T[(wm * 64 + mi * 32 + acc_row(r, lane)) * CG_TLD + wn * 64 + ni * 32 + (lane & 31)] = acc[mi][ni][r] * unscale;
     }
     __syncthreads();
-    gfloat* cov = as_global(cg_cov(dyn, n, t.layer));
-    const bool accumulate = cg_acc(dyn, n, t.layer) != 0;
+    gfloat* cov = as_global(cg_cov(dyn, n, L.src));
+    const bool accumulate = L.kind == 2 || cg_acc(dyn, n, L.src) != 0;      // a ring always subtracts from what its parent's assemble pass wrote
     const int D = L.g.D;
     for (int sb = 0; sb < t.mb / 2; ++sb) {                      // the 128 x 128 blocks of this tile
         const int ti = t.rb0 / 2 + sb, tj = t.cb0 / 2;
@@ -905,17 +1002,66 @@ __global__ __launch_bounds__(V2L_THREADS, 3) void nsgp_cov_group_syrk_kernel(con
     }
 }
 
+// R[dy][ca0 + r][col0 + c] = sum of the tile's range slabs, in range order (raw scaled sums; the assemble pass unscales)
+__global__ __launch_bounds__(256) void nsgp_cov_corr_reduce_kernel(const CovCorrUnit* __restrict__ units, const CovGroupLayer* __restrict__ layers,
+                                                                   const float* __restrict__ slabs, char* __restrict__ ws) {
+    const CovCorrUnit u = units[blockIdx.x];
+    const CovGroupLayer L = layers[u.layer];
+    float* __restrict__ R = reinterpret_cast<float*>(ws + L.r_off);
+    const int ld = 5 * L.Cp;
+    const float* __restrict__ base = slabs + (size_t)u.slab0 * (256 * 128);
+    for (int idx = threadIdx.x; idx < u.mb * 64 * 32; idx += 256) {
+        const int r = idx >> 5, c4 = (idx & 31) * 4;
+        if (u.ca0 + r >= L.Cp || u.col0 + c4 >= ld) continue;    // the junk half of a 64-channel layer's tile; column padding
+        f32x4 sum = *(const gf32x4*)(base + r * 128 + c4);
+        for (int s = 1; s < u.S; ++s) sum += *(const gf32x4*)(base + (size_t)s * (256 * 128) + r * 128 + c4);
+        *(gf32x4*)(R + ((long)u.dy * L.Cp + u.ca0 + r) * ld + u.col0 + c4) = sum;
+    }
+}
+
+// C[d1][d2] (=|+=) unscale * R[dy][ca][(dx + 2) Cp + cb] at the canonical orientation of the tap pair
+__global__ __launch_bounds__(256) void nsgp_cov_corr_assemble_kernel(const int* __restrict__ corr_layers, const int* __restrict__ prefix, int ncorr,
+                                                                     const CovGroupLayer* __restrict__ layers, int n, const void* __restrict__ dyn,
+                                                                     const char* __restrict__ ws, const unsigned* __restrict__ amax) {
+    const int k = cov_group_find(prefix, ncorr, blockIdx.x);
+    const CovGroupLayer L = layers[corr_layers[k]];
+    const int D = L.g.D, ld = 5 * L.Cp;
+    const float* __restrict__ R = reinterpret_cast<const float*>(ws + L.r_off);
+    const float sc = f2_scale_from_amax_bits(amax[L.src]);
+    const float unscale = (1.0f / sc) * (1.0f / sc);
+    gfloat* cov = as_global(cg_cov(dyn, n, L.src));
+    const bool accumulate = cg_acc(dyn, n, L.src) != 0;
+    const int d1_0 = (blockIdx.x - prefix[k]) * CG_ASM_ROWS;
+    for (int row = 0; row < CG_ASM_ROWS; ++row) {
+        const int d1 = d1_0 + row;
+        if (d1 >= D) break;
+        const int c1 = d1 / 9, t1 = d1 - 9 * c1, ky1 = t1 / 3, kx1 = t1 - 3 * ky1;
+        for (int d2 = threadIdx.x; d2 < D; d2 += 256) {
+            const int c2 = d2 / 9, t2 = d2 - 9 * c2, ky2 = t2 / 3, kx2 = t2 - 3 * ky2;
+            int dy = ky2 - ky1, dx = kx2 - kx1, ca = c1, cb = c2;
+            if (dy < 0 || (dy == 0 && (dx < 0 || (dx == 0 && c1 > c2)))) { dy = -dy; dx = -dx; ca = c2; cb = c1; }
+            const float v = as_global(R)[((long)dy * L.Cp + ca) * ld + (dx + 2) * L.Cp + cb] * unscale;
+            const long o = (long)d1 * D + d2;
+            cov[o] = accumulate ? (cov[o] + v) : v;
+        }
+    }
+}
+
 }  // namespace nsgp
 
 struct nsgp_cov_plan {
     int n = 0;                       // layers handed to create
     int n_group = 0;                 // of which on the grouped launches
+    int n_slots = 0;                 // entries of the layer table: grouped layers + one ring layer per correlation-form layer
+    int n_corr = 0;                  // layers in the correlation form
     std::vector<int> route;          // per layer: index into the grouped tables, or -1 (single-layer entry points)
+    std::vector<int> ring_parent;   // per table entry: its parent's index (rings) or -1
     size_t ws_bytes = 0, amax_off = 0;
-    int mean_units = 0, amax_units = 0, split_units = 0, n_tiles = 0;
+    int mean_units = 0, amax_units = 0, split_units = 0, n_tiles = 0, n_tiles_late = 0, corr_units = 0, asm_units = 0;
     nsgp::CovGroupLayer* d_layers = nullptr;
-    nsgp::CovGroupTile* d_tiles = nullptr;
-    int* d_prefix = nullptr;         // three prefix arrays of n_group + 1 ints: mean, amax, split
+    nsgp::CovGroupTile* d_tiles = nullptr;       // main tiles, then the rings' tiles
+    nsgp::CovCorrUnit* d_corr = nullptr;
+    int* d_prefix = nullptr;         // prefix arrays: mean, amax, split (n_slots + 1 each), assemble (n_corr + 1), then the n_corr layer indices
     size_t dyn_bytes = 0;
     char* h_dyn[4] = {nullptr, nullptr, nullptr, nullptr};
     char* d_dyn[4] = {nullptr, nullptr, nullptr, nullptr};
@@ -923,12 +1069,15 @@ struct nsgp_cov_plan {
     bool ev_used[4] = {false, false, false, false};
     int slot = 0;
     double flops_upper = 0;          // sum over grouped layers of L * D * (D + 128): the upper-triangle work actually needed
+    double tile_steps = 0;           // k32 steps of 256 x 128 tiles the SYRK launches execute (a 128-row tile counts half)
     size_t slab_off = 0;
-    struct SplitLayer { int group_index, D, Dp, S; size_t slab_base; };   // layers whose contraction is cut into S K ranges
+    struct SplitLayer { int group_index, D, Dp, S; size_t slab_base; };   // im2col layers whose contraction is cut into S K ranges
     std::vector<SplitLayer> split_layers;
 };
 
 namespace nsgp {
+static int g_cov_corr_mode = 1;      // 0: never the correlation form; 1: where it saves tile-steps (default); 2: wherever it applies
+
 static bool cov_group_eligible(const nsgp_cov_geom_t& q, int& D, int& L, int& Wo, int& Hp, int& Wp) {
     if (q.cin <= 0 || q.h <= 0 || q.w <= 0 || q.kh <= 0 || q.kw <= 0 || q.sh <= 0 || q.sw <= 0 || q.ph < 0 || q.pw < 0 || q.batch <= 0) return false;
     Hp = q.h + 2 * q.ph;
@@ -939,6 +1088,43 @@ static bool cov_group_eligible(const nsgp_cov_geom_t& q, int& D, int& L, int& Wo
     D = q.cin * q.kh * q.kw;
     L = Ho * Wo;
     return D % 64 == 0 && L >= 32;
+}
+static int cov_group_ranges(int nk, int max_steps, int& steps) {      // equal K ranges of at most max_steps
+    const int S0 = (nk + max_steps - 1) / max_steps;
+    steps = (nk + S0 - 1) / S0;
+    return (nk + steps - 1) / steps;
+}
+static double cov_im2col_tile_steps(int Dp, int Lp) {
+    double w = 0;
+    const int nt = cov2_tiles(Dp), nk = Lp / V2_BK;
+    for (int t = 0; t < nt; ++t) {
+        int rb0, cb0, mb;
+        cov2_tile_of(t, Dp, rb0, cb0, mb);
+        w += nk * (mb / 4.0);
+    }
+    return w;
+}
+// the correlation form's tiles: A row tiles over the dx = 0 copy, per dy the column tiles that hold a needed copy
+struct CorrShape { int Cp, Wq, Kq, rows_q, nk, step_a0, bstep1, n_rt, ct0_dy0, nct; };
+static CorrShape corr_shape(int C, int H, int W) {
+    CorrShape s;
+    s.Cp = (C + 63) / 64 * 64;
+    s.Wq = (W + 4 + 31) / 32 * 32;
+    s.Kq = (H + 4) * s.Wq;
+    s.rows_q = (5 * s.Cp + 127) / 128 * 128;
+    s.nk = H * s.Wq / V2_BK;                    // the image rows of the A operand: flat rows 2 .. H + 1
+    s.step_a0 = 2 * s.Wq / V2_BK;
+    s.bstep1 = s.Wq / V2_BK;
+    s.n_rt = (s.Cp / 64 + 3) / 4;               // 256-channel row tiles (the last may have 1-2 blocks: mb = 2)
+    s.ct0_dy0 = (2 * s.Cp / 64) / 2;            // dy = 0 needs the copies dx >= 0 only: column tiles from the one holding block 2 Cp / 64
+    s.nct = s.rows_q / 128;
+    return s;
+}
+static int corr_tile_mb(const CorrShape& s, int rt) { return (s.Cp / 64 - 4 * rt) >= 3 ? 4 : 2; }      // 3 blocks left: a full tile, its last block junk (never read back)
+static double corr_tile_steps(const CorrShape& s) {
+    double w = 0;
+    for (int rt = 0; rt < s.n_rt; ++rt) w += (corr_tile_mb(s, rt) / 4.0) * s.nk * ((s.nct - s.ct0_dy0) + 2 * s.nct);
+    return w;
 }
 }  // namespace nsgp
 
@@ -957,6 +1143,7 @@ extern "C" int nsgp_cov_plan_destroy(nsgp_cov_plan_t* P) {
     }
     if (P->d_layers) keep(hipFree(P->d_layers));
     if (P->d_tiles) keep(hipFree(P->d_tiles));
+    if (P->d_corr) keep(hipFree(P->d_corr));
     if (P->d_prefix) keep(hipFree(P->d_prefix));
     delete P;
     if (first != hipSuccess) return fail(NSGP_ERR_HIP, "nsgp_cov_plan_destroy: %s", hipGetErrorString(first));
@@ -970,63 +1157,143 @@ extern "C" int nsgp_cov_plan_create(nsgp_cov_plan_t** out, const nsgp_cov_geom_t
     P->n = n;
     P->route.assign(n, -1);
     std::vector<CovGroupLayer> ld;
-    std::vector<int> pm{0}, pa{0}, ps{0};
-    size_t off = 0;
     for (int i = 0; i < n; ++i) {
         const nsgp_cov_geom_t& q = geoms[i];
         int D, L, Wo, Hp, Wp;
         if (!cov_group_eligible(q, D, L, Wo, Hp, Wp)) continue;
         CovGroupLayer c{};
-        c.g = ConvGeom{D, L, Wo, q.kh, q.kw, q.sh, q.sw, Hp, Wp};
-        c.cin = q.cin; c.H = q.h; c.W = q.w; c.ph = q.ph; c.pw = q.pw; c.batch = q.batch;
-        c.Dp = cov2_pad_d(D);
-        c.Lp = cov2_pad_l(L);
-        c.needs_mean = !(q.batch == 1 && q.ph == 0 && q.pw == 0);
-        c.n_img = (long)q.cin * Hp * Wp;
-        c.xm_off = -1;
-        if (c.needs_mean) { c.xm_off = (long)off; off += align256((size_t)c.n_img * 4); }
+        c.cin = q.cin; c.H = q.h; c.W = q.w; c.batch = q.batch;
+        c.sign = 1.0f;
+        c.src = (int)ld.size();
+        c.xm_off = c.xt_off = c.r_off = -1;
+        // correlation form?  3 x 3, stride 1, padding 1, whole 64-channel blocks; by rule: its tile-steps (R tiles + the ring layer, plus
+        // the assemble pass priced at 5.3e-4 tile-steps per element of C: 12 B at ~4 TB/s against 5.7 ns per tile-step) under 0.8 x the im2col tiles'
+        bool corr = g_cov_corr_mode != 0 && q.kh == 3 && q.kw == 3 && q.sh == 1 && q.sw == 1 && q.ph == 1 && q.pw == 1 && q.cin % 64 == 0 && q.h >= 4 && q.w >= 4;
+        if (corr && g_cov_corr_mode == 1) {
+            const CorrShape s = corr_shape(q.cin, q.h, q.w);
+            const double old_steps = cov_im2col_tile_steps(cov2_pad_d(D), cov2_pad_l(L));
+            const double ring = cov_im2col_tile_steps(cov2_pad_d(D), cov2_pad_l(2 * (q.w + 2) + 2 * q.h));
+            const double new_steps = corr_tile_steps(s) + ring + 5.3e-4 * (double)D * D;
+            corr = new_steps < 0.8 * old_steps;
+        }
         P->route[i] = (int)ld.size();
+        P->flops_upper += (double)L * D * (D + 128.0);
+        if (!corr) {
+            c.kind = 0;
+            c.g = ConvGeom{D, L, Wo, q.kh, q.kw, q.sh, q.sw, Hp, Wp};
+            c.oy = -q.ph; c.ox = -q.pw;
+            c.Dp = cov2_pad_d(D);
+            c.Lp = cov2_pad_l(L);
+            c.needs_mean = !(q.batch == 1 && q.ph == 0 && q.pw == 0);
+            c.n_img = (long)q.cin * Hp * Wp;
+            ld.push_back(c);
+            continue;
+        }
+        const CorrShape s = corr_shape(q.cin, q.h, q.w);
+        c.kind = 1;
+        c.g = ConvGeom{D, L, q.w, 3, 3, 1, 1, q.h, q.w};
+        c.oy = c.ox = 0;
+        c.Dp = s.rows_q;
+        c.Lp = s.Kq;
+        c.Wq = s.Wq; c.Cp = s.Cp;
+        c.needs_mean = q.batch > 1;
+        c.n_img = (long)q.cin * q.h * q.w;
+        const int parent = (int)ld.size();
         ld.push_back(c);
+        ++P->n_corr;
+        // the ring: rows y = -1 and y = H (x in [-1, W]), columns x = -1 and x = W (y in [0, H - 1]) as ONE im2col layer over its
+        // 2 (W + 2) + 2 H positions (one tile per block of C: the subtraction is a plain read-modify-write)
+        CovGroupLayer r{};
+        r.kind = 2;
+        r.cin = q.cin; r.H = q.h; r.W = q.w; r.batch = q.batch;
+        r.g = ConvGeom{D, 2 * (q.w + 2) + 2 * q.h, 1, 3, 3, 1, 1, q.h, q.w};
+        r.Dp = cov2_pad_d(D);
+        r.Lp = cov2_pad_l(r.g.L);
+        r.needs_mean = c.needs_mean;      // reads its parent's image (xm_off copied below)
+        r.src = parent;
+        r.sign = -1.0f;
+        r.xm_off = r.xt_off = r.r_off = -1;
+        r.n_img = 0;
+        ld.push_back(r);
+    }
+    P->n_group = 0;
+    for (int i = 0; i < n; ++i) P->n_group += P->route[i] >= 0;
+    P->n_slots = (int)ld.size();
+    P->ring_parent.assign(ld.size(), -1);
+    size_t off = 0;
+    for (size_t li = 0; li < ld.size(); ++li) {
+        CovGroupLayer& c = ld[li];
+        if (c.kind == 2) { P->ring_parent[li] = c.src; c.xm_off = ld[c.src].xm_off; continue; }      // a ring follows its parent in the table
+        if (c.needs_mean) { c.xm_off = (long)off; off += align256((size_t)c.n_img * 4); }
     }
     for (CovGroupLayer& c : ld) { c.xt_off = (long)off; off += align256(v2_operand_bytes(c.Dp, c.Lp)); }
+    for (CovGroupLayer& c : ld)
+        if (c.kind == 1) { c.r_off = (long)off; off += align256((size_t)3 * c.Cp * 5 * c.Cp * 4); }
     P->amax_off = off;
     off += align256(std::max<size_t>(1, ld.size()) * sizeof(unsigned));
     P->ws_bytes = off;
-    P->n_group = (int)ld.size();
-    std::vector<CovGroupTile> tiles;
+    std::vector<int> pm{0}, pa{0}, ps{0}, pasm{0}, corr_ids;
+    std::vector<CovGroupTile> tiles, late;
+    std::vector<CovCorrUnit> cunits;
     size_t n_slabs = 0;
     for (size_t li = 0; li < ld.size(); ++li) {
         const CovGroupLayer& c = ld[li];
         const int chunks = (int)((c.n_img + CG_CHUNK - 1) / CG_CHUNK);
-        pm.push_back(pm.back() + (c.needs_mean ? chunks : 0));
-        pa.push_back(pa.back() + chunks);
+        pm.push_back(pm.back() + (c.needs_mean && c.kind != 2 ? chunks : 0));
+        pa.push_back(pa.back() + (c.kind == 2 ? 0 : chunks));
         ps.push_back(ps.back() + ((c.Lp / 8 + CG_SPLIT_OCTETS - 1) / CG_SPLIT_OCTETS) * (c.Dp / 64));
+        if (c.kind == 1) {
+            const CorrShape s = corr_shape(c.cin, c.H, c.W);
+            int steps;
+            const int S = cov_group_ranges(s.nk, CG_CORR_MAX_STEPS, steps);
+            for (int rt = 0; rt < s.n_rt; ++rt) {
+                const int mb = corr_tile_mb(s, rt);
+                for (int dy = 0; dy < 3; ++dy)
+                    for (int ct = (dy == 0 ? s.ct0_dy0 : 0); ct < s.nct; ++ct) {
+                        cunits.push_back(CovCorrUnit{(int)li, dy, rt * 256, mb, ct * 128, S, (long)n_slabs});
+                        for (int sp = 0; sp < S; ++sp)
+                            tiles.push_back(CovGroupTile{(int)li, 2 * s.Cp / 64 + 4 * rt, 2 * ct, mb, s.step_a0 + sp * steps, std::min(steps, s.nk - sp * steps),
+                                                         dy * s.bstep1, (long)(n_slabs + sp)});
+                        n_slabs += S;
+                        P->tile_steps += (mb / 4.0) * s.nk;
+                    }
+            }
+            corr_ids.push_back((int)li);
+            pasm.push_back(pasm.back() + (c.g.D + CG_ASM_ROWS - 1) / CG_ASM_ROWS);
+            continue;
+        }
         const int nt = cov2_tiles(c.Dp), nk = c.Lp / V2_BK;
-        const int S0 = (nk + CG_MAX_STEPS - 1) / CG_MAX_STEPS, steps = (nk + S0 - 1) / S0, S = (nk + steps - 1) / steps;
+        int steps;
+        const int S = c.kind == 2 ? 1 : cov_group_ranges(nk, CG_MAX_STEPS, steps);
+        if (c.kind == 2) steps = nk;
         if (S > 1) P->split_layers.push_back(nsgp_cov_plan::SplitLayer{(int)li, c.g.D, c.Dp, S, n_slabs});
+        std::vector<CovGroupTile>& dst = c.kind == 2 ? late : tiles;
         for (int t = 0; t < nt; ++t) {
             int rb0, cb0, mb;
             cov2_tile_of(t, c.Dp, rb0, cb0, mb);
-            if (S == 1) tiles.push_back(CovGroupTile{(int)li, rb0, cb0, mb, 0, nk, -1});
+            P->tile_steps += (mb / 4.0) * nk;
+            if (S == 1) dst.push_back(CovGroupTile{(int)li, rb0, cb0, mb, 0, nk, 0, -1});
             else
                 for (int sp = 0; sp < S; ++sp)      // slab layout of nsgp_cov_reduce_v2_kernel: [tile][range]
-                    tiles.push_back(CovGroupTile{(int)li, rb0, cb0, mb, sp * steps, std::min(steps, nk - sp * steps), (long)(n_slabs + (size_t)t * S + sp)});
+                    dst.push_back(CovGroupTile{(int)li, rb0, cb0, mb, sp * steps, std::min(steps, nk - sp * steps), 0, (long)(n_slabs + (size_t)t * S + sp)});
         }
         if (S > 1) n_slabs += (size_t)nt * S;
-        P->flops_upper += (double)c.g.L * c.g.D * (c.g.D + 128.0);
     }
     // longest contraction first: in-order dispatch is then LPT list scheduling on the one-workgroup CUs
-    std::stable_sort(tiles.begin(), tiles.end(), [&](const CovGroupTile& a, const CovGroupTile& b) {
-        const long ca = (long)a.nsteps * a.mb, cb = (long)b.nsteps * b.mb;
-        return ca > cb;
-    });
+    auto by_cost = [](const CovGroupTile& a, const CovGroupTile& b) { return (long)a.nsteps * a.mb > (long)b.nsteps * b.mb; };
+    std::stable_sort(tiles.begin(), tiles.end(), by_cost);
+    std::stable_sort(late.begin(), late.end(), by_cost);
     P->slab_off = P->ws_bytes;
     P->ws_bytes += align256(n_slabs * (size_t)(256 * 128) * 4);
     P->mean_units = pm.back();
     P->amax_units = pa.back();
     P->split_units = ps.back();
     P->n_tiles = (int)tiles.size();
-    P->dyn_bytes = align256((size_t)std::max(1, P->n_group) * (2 * sizeof(void*) + sizeof(int)));
+    P->n_tiles_late = (int)late.size();
+    P->corr_units = (int)cunits.size();
+    P->asm_units = pasm.back();
+    tiles.insert(tiles.end(), late.begin(), late.end());
+    P->dyn_bytes = align256((size_t)std::max(1, P->n_slots) * (2 * sizeof(void*) + sizeof(int)));
 #define COVP_HIP(call)                                                                               \
     do {                                                                                             \
         hipError_t e_ = (call);                                                                      \
@@ -1035,14 +1302,20 @@ extern "C" int nsgp_cov_plan_create(nsgp_cov_plan_t** out, const nsgp_cov_geom_t
             return fail(NSGP_ERR_HIP, "%s failed: %s", #call, hipGetErrorString(e_));                \
         }                                                                                            \
     } while (0)
-    if (P->n_group > 0) {
+    if (P->n_slots > 0) {
         COVP_HIP(hipMalloc(&P->d_layers, sizeof(CovGroupLayer) * ld.size()));
         COVP_HIP(hipMemcpy(P->d_layers, ld.data(), sizeof(CovGroupLayer) * ld.size(), hipMemcpyHostToDevice));
         COVP_HIP(hipMalloc(&P->d_tiles, sizeof(CovGroupTile) * tiles.size()));
         COVP_HIP(hipMemcpy(P->d_tiles, tiles.data(), sizeof(CovGroupTile) * tiles.size(), hipMemcpyHostToDevice));
+        if (!cunits.empty()) {
+            COVP_HIP(hipMalloc(&P->d_corr, sizeof(CovCorrUnit) * cunits.size()));
+            COVP_HIP(hipMemcpy(P->d_corr, cunits.data(), sizeof(CovCorrUnit) * cunits.size(), hipMemcpyHostToDevice));
+        }
         std::vector<int> prefix(pm);
         prefix.insert(prefix.end(), pa.begin(), pa.end());
         prefix.insert(prefix.end(), ps.begin(), ps.end());
+        prefix.insert(prefix.end(), pasm.begin(), pasm.end());
+        prefix.insert(prefix.end(), corr_ids.begin(), corr_ids.end());
         COVP_HIP(hipMalloc(&P->d_prefix, sizeof(int) * prefix.size()));
         COVP_HIP(hipMemcpy(P->d_prefix, prefix.data(), sizeof(int) * prefix.size(), hipMemcpyHostToDevice));
         for (int s = 0; s < 4; ++s) {
@@ -1068,22 +1341,35 @@ extern "C" int nsgp_cov_plan_routes(const nsgp_cov_plan_t* P, int* routes, int n
 extern "C" int nsgp_cov_plan_stats(const nsgp_cov_plan_t* P, int* n_grouped, int* n_tiles, double* upper_flops) {
     if (!P) return fail(NSGP_ERR_INVALID, "nsgp_cov_plan_stats: null plan");
     if (n_grouped) *n_grouped = P->n_group;
-    if (n_tiles) *n_tiles = P->n_tiles;
+    if (n_tiles) *n_tiles = P->n_tiles + P->n_tiles_late;
     if (upper_flops) *upper_flops = P->flops_upper;
     return NSGP_OK;
+}
+
+extern "C" int nsgp_cov_plan_forms(const nsgp_cov_plan_t* P, int* n_correlation_form, double* tile_steps) {
+    if (!P) return fail(NSGP_ERR_INVALID, "nsgp_cov_plan_forms: null plan");
+    if (n_correlation_form) *n_correlation_form = P->n_corr;
+    if (tile_steps) *tile_steps = P->tile_steps;
+    return NSGP_OK;
+}
+
+extern "C" int nsgp_cov_set_corr_mode(int mode) {
+    const int prev = g_cov_corr_mode;
+    g_cov_corr_mode = mode < 0 ? 0 : (mode > 2 ? 2 : mode);
+    return prev;
 }
 
 extern "C" int nsgp_cov_plan_run(nsgp_cov_plan_t* P, const float* const* x, float* const* cov, const int* accumulate, void* workspace,
                                  size_t workspace_bytes, void* stream_) {
     if (!P || !x || !cov || !accumulate) return fail(NSGP_ERR_INVALID, "nsgp_cov_plan_run: null argument");
-    if (P->n_group == 0) return NSGP_OK;
+    if (P->n_slots == 0) return NSGP_OK;
     if (!workspace || workspace_bytes < P->ws_bytes) return fail(NSGP_ERR_WORKSPACE, "nsgp_cov_plan_run: workspace %zu < %zu", workspace_bytes, P->ws_bytes);
     if (!aligned16(workspace)) return fail(NSGP_ERR_INVALID, "nsgp_cov_plan_run: workspace must be 16-byte aligned");
     hipStream_t stream = static_cast<hipStream_t>(stream_);
     const int s = P->slot;
     P->slot = (s + 1) % 4;
     if (P->ev_used[s]) NSGP_HIP(hipEventSynchronize(P->ev[s]));
-    const int ng = P->n_group;
+    const int ng = P->n_slots;
     const float** hx = reinterpret_cast<const float**>(P->h_dyn[s]);
     float** hc = reinterpret_cast<float**>(P->h_dyn[s]) + ng;
     int* ha = reinterpret_cast<int*>(reinterpret_cast<float**>(P->h_dyn[s]) + 2 * ng);
@@ -1095,11 +1381,15 @@ extern "C" int nsgp_cov_plan_run(nsgp_cov_plan_t* P, const float* const* x, floa
         hc[gi] = cov[i];
         ha[gi] = accumulate[i];
     }
+    for (int gi = 0; gi < ng; ++gi) {                            // the kernels address a ring through its parent's slot; keep its own slot valid
+        const int parent = P->ring_parent[gi];
+        if (parent >= 0) { hx[gi] = hx[parent]; hc[gi] = hc[parent]; ha[gi] = 1; }
+    }
     NSGP_HIP(hipMemcpyAsync(P->d_dyn[s], P->h_dyn[s], P->dyn_bytes, hipMemcpyHostToDevice, stream));
     char* ws = static_cast<char*>(workspace);
     unsigned* amax = reinterpret_cast<unsigned*>(ws + P->amax_off);
     NSGP_HIP(hipMemsetAsync(amax, 0, sizeof(unsigned) * ng, stream));
-    const int* pm = P->d_prefix, *pa = P->d_prefix + (ng + 1), *ps = P->d_prefix + 2 * (ng + 1);
+    const int* pm = P->d_prefix, *pa = pm + (ng + 1), *ps = pa + (ng + 1), *pasm = ps + (ng + 1), *corr_ids = pasm + (P->n_corr + 1);
     if (P->mean_units > 0) {
         hipLaunchKernelGGL(nsgp_cov_group_mean_kernel, dim3(P->mean_units), dim3(256), 0, stream, P->d_layers, pm, ng, (const void*)P->d_dyn[s], ws);
         NSGP_LAUNCH_CHECK();
@@ -1112,13 +1402,23 @@ extern "C" int nsgp_cov_plan_run(nsgp_cov_plan_t* P, const float* const* x, floa
     hipLaunchKernelGGL(nsgp_cov_group_syrk_kernel, dim3(P->n_tiles), dim3(V2L_THREADS), V2_SMEM_BYTES, stream, P->d_tiles, P->d_layers, ng,
                        (const void*)P->d_dyn[s], (const char*)ws, (const unsigned*)amax, slabs);
     NSGP_LAUNCH_CHECK();
-    for (const nsgp_cov_plan::SplitLayer& sl : P->split_layers) {      // the long contractions: ordered sum of their K ranges
+    for (const nsgp_cov_plan::SplitLayer& sl : P->split_layers) {      // the long im2col contractions: ordered sum of their K ranges
         const int nb128 = sl.Dp / 128;
         const long t128 = (long)nb128 * (nb128 + 1) / 2;
         int bands = 2;
         while (bands < 32 && t128 * bands < 256) bands *= 2;
         hipLaunchKernelGGL(nsgp_cov_reduce_v2_kernel, dim3((unsigned)t128, bands), dim3(256), 0, stream, slabs + sl.slab_base * (size_t)(256 * 128), sl.D, sl.Dp, sl.S,
                            128 / bands, hc[sl.group_index], ha[sl.group_index], (const unsigned*)(amax + sl.group_index));
+        NSGP_LAUNCH_CHECK();
+    }
+    if (P->n_corr > 0) {                                         // correlation form: R from the slabs, C from R, then the ring subtracted
+        hipLaunchKernelGGL(nsgp_cov_corr_reduce_kernel, dim3(P->corr_units), dim3(256), 0, stream, P->d_corr, P->d_layers, (const float*)slabs, ws);
+        NSGP_LAUNCH_CHECK();
+        hipLaunchKernelGGL(nsgp_cov_corr_assemble_kernel, dim3(P->asm_units), dim3(256), 0, stream, corr_ids, pasm, P->n_corr, P->d_layers, ng,
+                           (const void*)P->d_dyn[s], (const char*)ws, (const unsigned*)amax);
+        NSGP_LAUNCH_CHECK();
+        hipLaunchKernelGGL(nsgp_cov_group_syrk_kernel, dim3(P->n_tiles_late), dim3(V2L_THREADS), V2_SMEM_BYTES, stream, P->d_tiles + P->n_tiles, P->d_layers, ng,
+                           (const void*)P->d_dyn[s], (const char*)ws, (const unsigned*)amax, slabs);
         NSGP_LAUNCH_CHECK();
     }
     NSGP_HIP(hipEventRecord(P->ev[s], stream));

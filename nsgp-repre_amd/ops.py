@@ -154,6 +154,12 @@ def cov_set_split_mfma(mode: int) -> int:
     return int(_lib.load_library().nsgp_cov_set_split_mfma(int(mode)))
 
 
+def cov_set_corr_mode(mode: int) -> int:
+    """Correlation form of the 3x3 / stride 1 / padding 1 layers in ``CovGroupPlan`` (read when a plan is created): 0 never,
+    1 where it saves tile-steps (default), 2 wherever it applies.  Returns the previous mode."""
+    return int(_lib.load_library().nsgp_cov_set_corr_mode(int(mode)))
+
+
 def cov_workspace_bytes(cin, H, W, kernel_size, stride, padding) -> int:
     lib = _lib.load_library()
     return lib.nsgp_cov_workspace_bytes(cin, H, W, kernel_size[0], kernel_size[1], stride[0], stride[1],
@@ -188,6 +194,9 @@ class CovGroupPlan:
         ng, nt, fl = C.c_int(), C.c_int(), C.c_double()
         _lib.check(lib.nsgp_cov_plan_stats(self._handle, C.byref(ng), C.byref(nt), C.byref(fl)), "nsgp_cov_plan_stats")
         self.n_grouped, self.n_tiles, self.upper_flops = ng.value, nt.value, fl.value
+        nc, ts = C.c_int(), C.c_double()
+        _lib.check(lib.nsgp_cov_plan_forms(self._handle, C.byref(nc), C.byref(ts)), "nsgp_cov_plan_forms")
+        self.n_correlation_form, self.tile_steps = nc.value, ts.value
         self.device = device
         self._ws = None
 

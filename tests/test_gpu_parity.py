@@ -414,6 +414,55 @@ def test_grouped_covariance_pass_vs_single_layer_path_and_oracle(N, dev):
     assert col._plans == {} and col._group_ws is None
 
 
+def test_grouped_covariance_correlation_form(N, dev):
+    """The correlation form of the 3x3 / stride 1 / padding 1 layers (csrc/covariance.hip: Cov = the 25 shifted C x C correlations
+    laid out over the 81 tap pairs, minus the covariance of the ring of positions the shifts add) FORCED on geometries the rule would
+    leave alone: 64 channels (half of a 128-row tile is junk), 192 and 320 (a 3-block / 1-block remainder tile), widths that pad to
+    the next 32 with and without room, a 6 x 6 map (mostly ring), a contraction long enough to be cut into ranges, batch mean first --
+    against the oracle's unfold + mm at 1e-5 per row, bit-symmetric, bitwise reproducible, accumulating, and within the gate of
+    the im2col form of the same plan."""
+    from nsgp_repre_amd import ops
+    k3 = ((3, 3), (1, 1), (1, 1))
+    geoms = [(1, 64, 40, 56) + k3, (2, 64, 25, 42) + k3, (1, 128, 20, 28) + k3, (3, 192, 9, 13) + k3, (1, 256, 13, 21) + k3,
+             (1, 320, 10, 14) + k3, (1, 64, 6, 6) + k3, (1, 64, 64, 200) + k3, (1, 128, 30, 60, (1, 1), (1, 1), (0, 0))]
+    g = torch.Generator().manual_seed(31)
+    xs = [(torch.randn(b, c, h, w, generator=g).abs() * torch.pow(10.0, -2.0 * (torch.arange(c) % 5) / 4.0).view(1, c, 1, 1)) for b, c, h, w, *_ in geoms]
+    xd = [x.to(dev) for x in xs]
+    refs = [O.cov_conv2d(x, gm[4], gm[5], gm[6]) for x, gm in zip(xs, geoms)]
+    res = {}
+    for mode in (2, 0):
+        prev = ops.cov_set_corr_mode(mode)
+        try:
+            plan = ops.CovGroupPlan(geoms, dev)
+        finally:
+            ops.cov_set_corr_mode(prev)
+        assert plan.routes == [True] * len(geoms)
+        assert plan.n_correlation_form == (8 if mode == 2 else 0)
+        covs = plan.run(xd, [None] * len(geoms))
+        again = plan.run(xd, [None] * len(geoms))
+        for i, ref in enumerate(refs):
+            assert _row_rel(covs[i], ref) <= REL and _rel(covs[i], ref) <= REL, (mode, i, _row_rel(covs[i], ref))
+            assert torch.equal(covs[i], covs[i].t().contiguous()), (mode, i)
+            assert torch.equal(covs[i], again[i]), (mode, i, "not reproducible")
+        x2 = [(x * 0.5 + 0.1).to(dev) for x in xs]
+        acc = plan.run(x2, [c.clone() for c in covs])
+        for i, (x, gm) in enumerate(zip(xs, geoms)):
+            assert _rel(acc[i], refs[i] + O.cov_conv2d(x * 0.5 + 0.1, gm[4], gm[5], gm[6])) <= REL, (mode, i)
+        # wide dynamic range and zeros: the per-layer scale follows
+        for f in (1e4, 1e-6, 0.0):
+            c2 = plan.run([x * f for x in xd], [None] * len(geoms))
+            for i, ref in enumerate(refs):
+                assert torch.isfinite(c2[i]).all() and _rel(c2[i], ref * f * f) <= REL, (mode, i, f)
+        plan.close()
+        res[mode] = covs
+    for i in range(len(geoms)):
+        assert _rel(res[2][i], res[0][i]) <= REL, i
+    # the rule on its own: large maps take the form, small ones and everything that is not 3x3 / 1 / 1 do not
+    plan = ops.CovGroupPlan([(1, 64, 100, 168) + k3, (1, 512, 7, 11) + k3, (1, 64, 100, 168, (3, 3), (2, 2), (1, 1))], dev)
+    assert plan.n_correlation_form == 1
+    plan.close()
+
+
 @pytest.mark.parametrize("mode", [0, 2, 3, 4])
 @pytest.mark.parametrize("name", list(_TRUE_SIZE))
 def test_covariance_at_true_size(N, dev, name, mode):
@@ -437,6 +486,7 @@ def test_covariance_at_true_size(N, dev, name, mode):
             assert (cin * k * k) % 64 != 0       # the 7x7 stem stays on the single-layer entry point
             plan.close()
             return
+        assert plan.n_correlation_form == int(name == "neck.fpn_convs.0.conv")     # by rule: the 3x3 / 1 / 1 layer on the large map
         cov = plan.run([xd], [None])[0]
         torch.cuda.synchronize()
         plan.close()
