@@ -134,7 +134,8 @@ def _covariance_forward_ms(dev, depth, only_grouped=False):
             e0.record(); fn(); e1.record(); torch.cuda.synchronize()
             ts.append(e0.elapsed_time(e1))
         out.append(sorted(ts)[1])
-    stats = dict(grouped_layers=plan.n_grouped, tiles=plan.n_tiles, upper_triangle_flops=plan.upper_flops, workspace_gb=plan.workspace_bytes / 1e9)
+    stats = dict(grouped_layers=plan.n_grouped, tiles=plan.n_tiles, upper_triangle_flops=plan.upper_flops, workspace_gb=plan.workspace_bytes / 1e9,
+                 layers_in_correlation_form=plan.n_correlation_form, tile_steps=plan.tile_steps)
     plan.close()
     return out[0], out[1], out[2], ref_flops, len(layers), stats
 

@@ -715,23 +715,26 @@ namespace nsgp {
 //   R tiles:   A = the dx = 0 copy (C rows), B = all copies read dy Wq / 32 k-steps further on -- the same tile function, a byte
 //              offset on B.  dy = 0 needs dx >= 0 only.  13 C^2 instead of 40.5 C^2 products per position: ~2.5-2.8 x fewer
 //              tile-steps net of the row-pitch padding.  Contractions are cut into ranges of <= CG_CORR_MAX_STEPS, raw sums to slabs;
-//   nsgp_cov_corr_reduce_kernel    R[dy][c1][(dx, c2)] = ordered sum of the range slabs;
-//   nsgp_cov_corr_assemble_kernel  C[d1][d2] (=|+=) unscale * R at the canonical orientation of the pair (dy > 0, or dy = 0 and dx > 0,
-//              or the same tap and c1 <= c2): (d1,d2) and (d2,d1) read the same number, C stays bit-symmetric;
-//   ring:      ONE more im2col layer per parent whose columns are the ring's positions (rows y = -1, H and columns x = -1, W), through the
-//              ordinary tiles in a second, small SYRK launch whose epilogue SUBTRACTS.
+//   nsgp_cov_corr_reduce_kernel    R[dy][dx][c1][c2] = ordered sum of the range slabs, and its transpose into R[-dy][-dx] (all 25 shifts);
+//   nsgp_cov_corr_assemble_kernel  C[d1][d2] (=|+=) unscale * R[ky2-ky1][kx2-kx1][c1][c2] - strips: (d1,d2) and (d2,d1) read two copies of the same
+//              number, C stays bit-symmetric;
+//   ring:      at a ring position only one row or column of the 3x3 window is inside the image, so the ring's covariance lives in the tap
+//              pairs of that row / column: four STRIP layers per parent (top y = -1: taps ky = 2; bottom y = H: ky = 0; left x = -1:
+//              kx = 2; right x = W: kx = 0; rows (c, the free tap index), D = 3 C, L = W + 2 or H) go through the ordinary tiles of the
+//              same launch into [3C x 3C] buffers, and the assemble pass subtracts them where they apply.
 // Chosen per layer by tile-step count (plan creation; nsgp_cov_set_corr_mode forces it on or off for tests and studies).
 struct CovGroupLayer {
     ConvGeom g;              // kinds 0 / 2: im2col geometry over the window; kind 1: D = 9 C, L = H W, Hp = H, Wp = W (the raw image)
-    int kind;                // 0 im2col layer; 1 correlation form; 2 the ring of a kind-1 layer
+    int kind;                // 0 im2col layer; 1 correlation form; 2 one of the four ring strips of a kind-1 layer (D = 3 C)
     int cin, H, W, batch;    // the hooked input [batch x cin x H x W]
     int oy, ox;              // window origin in image coordinates (window = g.Hp x g.Wp; outside the image: zero)
     int Dp, Lp;              // operand rows, contraction length (kind 1: pad128(5 Cp) rows, (H + 4) Wq)
     int needs_mean;          // 0: the input is its own batch mean and needs no border (B == 1 and no padding, or kind 1 with B == 1)
-    int src;                 // slot of x / cov / accumulate / amax in the per-run tables (a ring: its parent's)
-    float sign;              // +1; rings: -1
+    int src;                 // slot of x / cov / accumulate / amax in the per-run tables (a strip: its parent's)
     int Wq, Cp;              // kind 1: flat row pitch (a multiple of 32), channels padded to 64
-    long xm_off, xt_off, r_off;   // byte offsets into the workspace (-1: none)
+    int strip;               // kind 2: 0 top (y = -1), 1 bottom (y = H), 2 left (x = -1), 3 right (x = W)
+    long xm_off, xt_off, r_off;   // byte offsets into the workspace (-1: none); r_off: kind 1 its R, kind 2 its [3C x 3C] strip covariance
+    long s_off[4];           // kind 1: the r_off of its four strips
     long n_img;              // elements of the window image
 };
 struct CovGroupTile {
@@ -761,7 +764,7 @@ constexpr int CG_CHUNK = 256 * 64;       // elements per workgroup of the mean /
 constexpr int CG_MAX_STEPS = 600;
 constexpr int CG_CORR_MAX_STEPS = 320;   // correlation tiles: few tiles per layer (26 for C = 256), so shorter ranges also balance the launch
 constexpr int CG_SPLIT_OCTETS = 16;      // l-octets per workgroup of the operand-split launch (4 per wave)
-constexpr int CG_ASM_ROWS = 4;           // rows of C per workgroup of the assemble launch
+constexpr int CG_ASM_ROWS = 8;           // rows of C per workgroup of the assemble launch
 
 // dyn: [x pointers n][cov pointers n][accumulate flags n]
 __device__ __forceinline__ const float* cg_x(const void* dyn, int i) { return reinterpret_cast<const float* const*>(dyn)[i]; }
@@ -873,11 +876,10 @@ __global__ __launch_bounds__(256) void nsgp_cov_group_split_kernel(const CovGrou
         return;
     }
     if (L.kind == 2) {
-        // ring operand: column l is ring position l -- the rows y = -1 and y = H (x = -1 .. W), then the columns x = -1 and x = W
-        // (y = 0 .. H - 1) -- of the parent's image, row d = (c, ky, kx) reads X[c][y + ky - 1][x + kx - 1] (zero outside)
-        const int c = d / 9, tap = d - 9 * c, ky = tap / 3, kx = tap - 3 * ky;
+        // strip operand: row d = (c, k), column l = position along the strip.  top / bottom: X[c][0 | H-1][l + k - 2] (l = x + 1, k = kx);
+        // left / right: X[c][l + k - 1][0 | W-1] (l = y, k = ky); zero outside the image
+        const int c = d / 3, k = d - 3 * c;
         const float* __restrict__ img = xm + (long)c * L.H * L.W;
-        const int w2 = L.W + 2;
 #pragma unroll
         for (int i = 0; i < CG_SPLIT_OCTETS / 4; ++i) {
             const int o = ob * CG_SPLIT_OCTETS + 4 * i + wave;
@@ -890,12 +892,9 @@ __global__ __launch_bounds__(256) void nsgp_cov_group_split_kernel(const CovGrou
                 for (int e = 0; e < 8; ++e) {
                     const int l = o * 8 + e;
                     if (l >= L.g.L) break;
-                    int y, x;
-                    if (l < w2) { y = -1; x = l - 1; }
-                    else if (l < 2 * w2) { y = L.H; x = l - w2 - 1; }
-                    else if (l < 2 * w2 + L.H) { y = l - 2 * w2; x = -1; }
-                    else { y = l - 2 * w2 - L.H; x = L.W; }
-                    const int iy = y + ky - 1, ix = x + kx - 1;
+                    int iy, ix;
+                    if (L.strip < 2) { iy = L.strip == 0 ? 0 : L.H - 1; ix = l + k - 2; }
+                    else { iy = l + k - 1; ix = L.strip == 2 ? 0 : L.W - 1; }
                     if (iy >= 0 && iy < L.H && ix >= 0 && ix < L.W) v[e >> 2][e & 3] = as_global(img)[(long)iy * L.W + ix];
                 }
             }
@@ -951,7 +950,7 @@ __global__ __launch_bounds__(V2L_THREADS, 3) void nsgp_cov_group_syrk_kernel(con
     // park the unscaled 256 (128) x 128 block in LDS
     float* T = reinterpret_cast<float*>(smem_c);
     const float sc = f2_scale_from_amax_bits(amax[L.src]);
-    const float unscale = L.sign * ((1.0f / sc) * (1.0f / sc));
+    const float unscale = (1.0f / sc) * (1.0f / sc);
     if (wave < 2 * t.mb) {
         const int wm = wave >> 1, wn = wave & 1;
 #pragma unroll
@@ -963,8 +962,9 @@ __global__ __launch_bounds__(V2L_THREADS, 3) void nsgp_cov_group_syrk_kernel(con
                     T[(wm * 64 + mi * 32 + acc_row(r, lane)) * CG_TLD + wn * 64 + ni * 32 + (lane & 31)] = acc[mi][ni][r] * unscale;
     }
     __syncthreads();
-    gfloat* cov = as_global(cg_cov(dyn, n, L.src));
-    const bool accumulate = L.kind == 2 || cg_acc(dyn, n, L.src) != 0;      // a ring always subtracts from what its parent's assemble pass wrote
+    // a strip's covariance goes to its buffer in the workspace (the assemble pass of its parent reads it)
+    gfloat* cov = as_global(L.kind == 2 ? reinterpret_cast<float*>(const_cast<char*>(ws) + L.r_off) : cg_cov(dyn, n, L.src));
+    const bool accumulate = L.kind != 2 && cg_acc(dyn, n, L.src) != 0;
     const int D = L.g.D;
     for (int sb = 0; sb < t.mb / 2; ++sb) {                      // the 128 x 128 blocks of this tile
         const int ti = t.rb0 / 2 + sb, tj = t.cb0 / 2;
@@ -1002,45 +1002,72 @@ __global__ __launch_bounds__(V2L_THREADS, 3) void nsgp_cov_group_syrk_kernel(con
     }
 }
 
-// R[dy][ca0 + r][col0 + c] = sum of the tile's range slabs, in range order (raw scaled sums; the assemble pass unscales)
+// R[dy+2][dx+2][ca][cb] = sum of the tile's range slabs, in range order (raw scaled sums; the assemble pass unscales), AND its transpose
+// into the opposite shift, R[2-dy][2-dx][cb][ca]: the assemble pass then reads every tap pair along a row of some R (cb contiguous
+// across lanes), and (d1,d2) / (d2,d1) read two copies of the same number.  Shift 0: the upper triangle serves both halves.
 __global__ __launch_bounds__(256) void nsgp_cov_corr_reduce_kernel(const CovCorrUnit* __restrict__ units, const CovGroupLayer* __restrict__ layers,
                                                                    const float* __restrict__ slabs, char* __restrict__ ws) {
     const CovCorrUnit u = units[blockIdx.x];
     const CovGroupLayer L = layers[u.layer];
-    float* __restrict__ R = reinterpret_cast<float*>(ws + L.r_off);
-    const int ld = 5 * L.Cp;
+    gfloat* R = as_global(reinterpret_cast<float*>(ws + L.r_off));
+    const int Cp = L.Cp;
+    const long plane = (long)Cp * Cp;
     const float* __restrict__ base = slabs + (size_t)u.slab0 * (256 * 128);
-    for (int idx = threadIdx.x; idx < u.mb * 64 * 32; idx += 256) {
-        const int r = idx >> 5, c4 = (idx & 31) * 4;
-        if (u.ca0 + r >= L.Cp || u.col0 + c4 >= ld) continue;    // the junk half of a 64-channel layer's tile; column padding
+    const int band_rows = u.mb * 64 / (int)gridDim.y;            // grid.y bands of rows: 26 tiles per 256-channel layer alone would leave most CUs idle
+    for (int idx = threadIdx.x; idx < band_rows * 32; idx += 256) {
+        const int r = blockIdx.y * band_rows + (idx >> 5), c4 = (idx & 31) * 4;
+        const int ca = u.ca0 + r, col = u.col0 + c4;             // col = j Cp + cb; Cp % 64 == 0: the four columns share j
+        if (ca >= Cp || col >= 5 * Cp) continue;                 // the junk half of a 64-channel layer's tile; column padding
         f32x4 sum = *(const gf32x4*)(base + r * 128 + c4);
         for (int s = 1; s < u.S; ++s) sum += *(const gf32x4*)(base + (size_t)s * (256 * 128) + r * 128 + c4);
-        *(gf32x4*)(R + ((long)u.dy * L.Cp + u.ca0 + r) * ld + u.col0 + c4) = sum;
+        const int j = col / Cp, cb = col - j * Cp, dx = j - 2;
+        if (u.dy == 0 && dx < 0) continue;                       // not needed (a tile that straddles the dx = -1 / 0 boundary)
+        gfloat* fwd = R + ((long)(u.dy + 2) * 5 + j) * plane;
+        gfloat* bwd = R + ((long)(2 - u.dy) * 5 + (2 - dx)) * plane;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            if (u.dy == 0 && dx == 0) {
+                if (ca <= cb + e) { fwd[(long)ca * Cp + cb + e] = sum[e]; fwd[(long)(cb + e) * Cp + ca] = sum[e]; }
+            } else {
+                fwd[(long)ca * Cp + cb + e] = sum[e];
+                bwd[(long)(cb + e) * Cp + ca] = sum[e];
+            }
+        }
     }
 }
 
-// C[d1][d2] (=|+=) unscale * R[dy][ca][(dx + 2) Cp + cb] at the canonical orientation of the tap pair
+// C[d1][d2] (=|+=) unscale * R[ky2-ky1+2][kx2-kx1+2][c1][c2] - the strips that hold the tap pair.
+// A workgroup owns CG_ASM_ROWS rows of C; a thread keeps its column's (c2, ky2, kx2) over the rows.
 __global__ __launch_bounds__(256) void nsgp_cov_corr_assemble_kernel(const int* __restrict__ corr_layers, const int* __restrict__ prefix, int ncorr,
                                                                      const CovGroupLayer* __restrict__ layers, int n, const void* __restrict__ dyn,
                                                                      const char* __restrict__ ws, const unsigned* __restrict__ amax) {
     const int k = cov_group_find(prefix, ncorr, blockIdx.x);
     const CovGroupLayer L = layers[corr_layers[k]];
-    const int D = L.g.D, ld = 5 * L.Cp;
-    const float* __restrict__ R = reinterpret_cast<const float*>(ws + L.r_off);
+    const int D = L.g.D, ld3 = 3 * L.cin;
+    const gfloat* R = as_global(reinterpret_cast<const float*>(ws + L.r_off));
+    const gfloat* s_top = as_global(reinterpret_cast<const float*>(ws + L.s_off[0]));
+    const gfloat* s_bot = as_global(reinterpret_cast<const float*>(ws + L.s_off[1]));
+    const gfloat* s_lft = as_global(reinterpret_cast<const float*>(ws + L.s_off[2]));
+    const gfloat* s_rgt = as_global(reinterpret_cast<const float*>(ws + L.s_off[3]));
     const float sc = f2_scale_from_amax_bits(amax[L.src]);
     const float unscale = (1.0f / sc) * (1.0f / sc);
     gfloat* cov = as_global(cg_cov(dyn, n, L.src));
     const bool accumulate = cg_acc(dyn, n, L.src) != 0;
     const int d1_0 = (blockIdx.x - prefix[k]) * CG_ASM_ROWS;
-    for (int row = 0; row < CG_ASM_ROWS; ++row) {
-        const int d1 = d1_0 + row;
-        if (d1 >= D) break;
-        const int c1 = d1 / 9, t1 = d1 - 9 * c1, ky1 = t1 / 3, kx1 = t1 - 3 * ky1;
-        for (int d2 = threadIdx.x; d2 < D; d2 += 256) {
-            const int c2 = d2 / 9, t2 = d2 - 9 * c2, ky2 = t2 / 3, kx2 = t2 - 3 * ky2;
-            int dy = ky2 - ky1, dx = kx2 - kx1, ca = c1, cb = c2;
-            if (dy < 0 || (dy == 0 && (dx < 0 || (dx == 0 && c1 > c2)))) { dy = -dy; dx = -dx; ca = c2; cb = c1; }
-            const float v = as_global(R)[((long)dy * L.Cp + ca) * ld + (dx + 2) * L.Cp + cb] * unscale;
+    for (int d2 = threadIdx.x; d2 < D; d2 += 256) {
+        const int c2 = d2 / 9, t2 = d2 - 9 * c2, ky2 = t2 / 3, kx2 = t2 - 3 * ky2;
+#pragma unroll 4
+        for (int row = 0; row < CG_ASM_ROWS; ++row) {
+            const int d1 = d1_0 + row;                         // uniform
+            if (d1 >= D) break;
+            const int c1 = d1 / 9, t1 = d1 - 9 * c1, ky1 = t1 / 3, kx1 = t1 - 3 * ky1;
+            float v = R[(((long)(ky2 - ky1 + 2) * 5 + (kx2 - kx1 + 2)) * L.Cp + c1) * L.Cp + c2] * unscale;
+            float sub = 0.0f;                                  // fixed order, symmetric operands: (d1,d2) and (d2,d1) subtract the same number
+            if (ky1 == 2 && ky2 == 2) sub += s_top[(long)(3 * c1 + kx1) * ld3 + 3 * c2 + kx2];
+            if (ky1 == 0 && ky2 == 0) sub += s_bot[(long)(3 * c1 + kx1) * ld3 + 3 * c2 + kx2];
+            if (kx1 == 2 && kx2 == 2) sub += s_lft[(long)(3 * c1 + ky1) * ld3 + 3 * c2 + ky2];
+            if (kx1 == 0 && kx2 == 0) sub += s_rgt[(long)(3 * c1 + ky1) * ld3 + 3 * c2 + ky2];
+            v -= sub;
             const long o = (long)d1 * D + d2;
             cov[o] = accumulate ? (cov[o] + v) : v;
         }
@@ -1055,11 +1082,11 @@ struct nsgp_cov_plan {
     int n_slots = 0;                 // entries of the layer table: grouped layers + one ring layer per correlation-form layer
     int n_corr = 0;                  // layers in the correlation form
     std::vector<int> route;          // per layer: index into the grouped tables, or -1 (single-layer entry points)
-    std::vector<int> ring_parent;   // per table entry: its parent's index (rings) or -1
+    std::vector<int> ring_parent;   // per table entry: its parent's index (strips) or -1
     size_t ws_bytes = 0, amax_off = 0;
-    int mean_units = 0, amax_units = 0, split_units = 0, n_tiles = 0, n_tiles_late = 0, corr_units = 0, asm_units = 0;
+    int mean_units = 0, amax_units = 0, split_units = 0, n_tiles = 0, corr_units = 0, asm_units = 0;
     nsgp::CovGroupLayer* d_layers = nullptr;
-    nsgp::CovGroupTile* d_tiles = nullptr;       // main tiles, then the rings' tiles
+    nsgp::CovGroupTile* d_tiles = nullptr;
     nsgp::CovCorrUnit* d_corr = nullptr;
     int* d_prefix = nullptr;         // prefix arrays: mean, amax, split (n_slots + 1 each), assemble (n_corr + 1), then the n_corr layer indices
     size_t dyn_bytes = 0;
@@ -1163,16 +1190,15 @@ extern "C" int nsgp_cov_plan_create(nsgp_cov_plan_t** out, const nsgp_cov_geom_t
         if (!cov_group_eligible(q, D, L, Wo, Hp, Wp)) continue;
         CovGroupLayer c{};
         c.cin = q.cin; c.H = q.h; c.W = q.w; c.batch = q.batch;
-        c.sign = 1.0f;
         c.src = (int)ld.size();
         c.xm_off = c.xt_off = c.r_off = -1;
-        // correlation form?  3 x 3, stride 1, padding 1, whole 64-channel blocks; by rule: its tile-steps (R tiles + the ring layer, plus
+        // correlation form?  3 x 3, stride 1, padding 1, whole 64-channel blocks; by rule: its tile-steps (R tiles + the four strips, plus
         // the assemble pass priced at 5.3e-4 tile-steps per element of C: 12 B at ~4 TB/s against 5.7 ns per tile-step) under 0.8 x the im2col tiles'
         bool corr = g_cov_corr_mode != 0 && q.kh == 3 && q.kw == 3 && q.sh == 1 && q.sw == 1 && q.ph == 1 && q.pw == 1 && q.cin % 64 == 0 && q.h >= 4 && q.w >= 4;
         if (corr && g_cov_corr_mode == 1) {
             const CorrShape s = corr_shape(q.cin, q.h, q.w);
             const double old_steps = cov_im2col_tile_steps(cov2_pad_d(D), cov2_pad_l(L));
-            const double ring = cov_im2col_tile_steps(cov2_pad_d(D), cov2_pad_l(2 * (q.w + 2) + 2 * q.h));
+            const double ring = 2 * cov_im2col_tile_steps(cov2_pad_d(3 * q.cin), cov2_pad_l(q.w + 2)) + 2 * cov_im2col_tile_steps(cov2_pad_d(3 * q.cin), cov2_pad_l(q.h));
             const double new_steps = corr_tile_steps(s) + ring + 5.3e-4 * (double)D * D;
             corr = new_steps < 0.8 * old_steps;
         }
@@ -1201,20 +1227,21 @@ extern "C" int nsgp_cov_plan_create(nsgp_cov_plan_t** out, const nsgp_cov_geom_t
         const int parent = (int)ld.size();
         ld.push_back(c);
         ++P->n_corr;
-        // the ring: rows y = -1 and y = H (x in [-1, W]), columns x = -1 and x = W (y in [0, H - 1]) as ONE im2col layer over its
-        // 2 (W + 2) + 2 H positions (one tile per block of C: the subtraction is a plain read-modify-write)
-        CovGroupLayer r{};
-        r.kind = 2;
-        r.cin = q.cin; r.H = q.h; r.W = q.w; r.batch = q.batch;
-        r.g = ConvGeom{D, 2 * (q.w + 2) + 2 * q.h, 1, 3, 3, 1, 1, q.h, q.w};
-        r.Dp = cov2_pad_d(D);
-        r.Lp = cov2_pad_l(r.g.L);
-        r.needs_mean = c.needs_mean;      // reads its parent's image (xm_off copied below)
-        r.src = parent;
-        r.sign = -1.0f;
-        r.xm_off = r.xt_off = r.r_off = -1;
-        r.n_img = 0;
-        ld.push_back(r);
+        // the ring: rows y = -1 and y = H (x in [-1, W]), columns x = -1 and x = W (y in [0, H - 1]) as four strip layers of D = 3 C
+        for (int k = 0; k < 4; ++k) {
+            CovGroupLayer r{};
+            r.kind = 2;
+            r.strip = k;
+            r.cin = q.cin; r.H = q.h; r.W = q.w; r.batch = q.batch;
+            r.g = ConvGeom{3 * q.cin, k < 2 ? q.w + 2 : q.h, 1, 3, 3, 1, 1, q.h, q.w};
+            r.Dp = cov2_pad_d(r.g.D);
+            r.Lp = cov2_pad_l(r.g.L);
+            r.needs_mean = c.needs_mean;      // reads its parent's image (xm_off copied below)
+            r.src = parent;
+            r.xm_off = r.xt_off = r.r_off = -1;
+            r.n_img = 0;
+            ld.push_back(r);
+        }
     }
     P->n_group = 0;
     for (int i = 0; i < n; ++i) P->n_group += P->route[i] >= 0;
@@ -1223,17 +1250,24 @@ extern "C" int nsgp_cov_plan_create(nsgp_cov_plan_t** out, const nsgp_cov_geom_t
     size_t off = 0;
     for (size_t li = 0; li < ld.size(); ++li) {
         CovGroupLayer& c = ld[li];
-        if (c.kind == 2) { P->ring_parent[li] = c.src; c.xm_off = ld[c.src].xm_off; continue; }      // a ring follows its parent in the table
+        if (c.kind == 2) { P->ring_parent[li] = c.src; c.xm_off = ld[c.src].xm_off; continue; }      // a strip follows its parent in the table
         if (c.needs_mean) { c.xm_off = (long)off; off += align256((size_t)c.n_img * 4); }
     }
     for (CovGroupLayer& c : ld) { c.xt_off = (long)off; off += align256(v2_operand_bytes(c.Dp, c.Lp)); }
-    for (CovGroupLayer& c : ld)
-        if (c.kind == 1) { c.r_off = (long)off; off += align256((size_t)3 * c.Cp * 5 * c.Cp * 4); }
+    for (size_t li = 0; li < ld.size(); ++li) {
+        CovGroupLayer& c = ld[li];
+        if (c.kind == 1) { c.r_off = (long)off; off += align256((size_t)25 * c.Cp * c.Cp * 4); }
+        if (c.kind == 2) {
+            c.r_off = (long)off;
+            off += align256((size_t)c.g.D * c.g.D * 4);
+            ld[c.src].s_off[c.strip] = c.r_off;
+        }
+    }
     P->amax_off = off;
     off += align256(std::max<size_t>(1, ld.size()) * sizeof(unsigned));
     P->ws_bytes = off;
     std::vector<int> pm{0}, pa{0}, ps{0}, pasm{0}, corr_ids;
-    std::vector<CovGroupTile> tiles, late;
+    std::vector<CovGroupTile> tiles;
     std::vector<CovCorrUnit> cunits;
     size_t n_slabs = 0;
     for (size_t li = 0; li < ld.size(); ++li) {
@@ -1267,7 +1301,7 @@ extern "C" int nsgp_cov_plan_create(nsgp_cov_plan_t** out, const nsgp_cov_geom_t
         const int S = c.kind == 2 ? 1 : cov_group_ranges(nk, CG_MAX_STEPS, steps);
         if (c.kind == 2) steps = nk;
         if (S > 1) P->split_layers.push_back(nsgp_cov_plan::SplitLayer{(int)li, c.g.D, c.Dp, S, n_slabs});
-        std::vector<CovGroupTile>& dst = c.kind == 2 ? late : tiles;
+        std::vector<CovGroupTile>& dst = tiles;
         for (int t = 0; t < nt; ++t) {
             int rb0, cb0, mb;
             cov2_tile_of(t, c.Dp, rb0, cb0, mb);
@@ -1282,17 +1316,14 @@ extern "C" int nsgp_cov_plan_create(nsgp_cov_plan_t** out, const nsgp_cov_geom_t
     // longest contraction first: in-order dispatch is then LPT list scheduling on the one-workgroup CUs
     auto by_cost = [](const CovGroupTile& a, const CovGroupTile& b) { return (long)a.nsteps * a.mb > (long)b.nsteps * b.mb; };
     std::stable_sort(tiles.begin(), tiles.end(), by_cost);
-    std::stable_sort(late.begin(), late.end(), by_cost);
     P->slab_off = P->ws_bytes;
     P->ws_bytes += align256(n_slabs * (size_t)(256 * 128) * 4);
     P->mean_units = pm.back();
     P->amax_units = pa.back();
     P->split_units = ps.back();
     P->n_tiles = (int)tiles.size();
-    P->n_tiles_late = (int)late.size();
     P->corr_units = (int)cunits.size();
     P->asm_units = pasm.back();
-    tiles.insert(tiles.end(), late.begin(), late.end());
     P->dyn_bytes = align256((size_t)std::max(1, P->n_slots) * (2 * sizeof(void*) + sizeof(int)));
 #define COVP_HIP(call)                                                                               \
     do {                                                                                             \
@@ -1341,7 +1372,7 @@ extern "C" int nsgp_cov_plan_routes(const nsgp_cov_plan_t* P, int* routes, int n
 extern "C" int nsgp_cov_plan_stats(const nsgp_cov_plan_t* P, int* n_grouped, int* n_tiles, double* upper_flops) {
     if (!P) return fail(NSGP_ERR_INVALID, "nsgp_cov_plan_stats: null plan");
     if (n_grouped) *n_grouped = P->n_group;
-    if (n_tiles) *n_tiles = P->n_tiles + P->n_tiles_late;
+    if (n_tiles) *n_tiles = P->n_tiles;
     if (upper_flops) *upper_flops = P->flops_upper;
     return NSGP_OK;
 }
@@ -1381,7 +1412,7 @@ extern "C" int nsgp_cov_plan_run(nsgp_cov_plan_t* P, const float* const* x, floa
         hc[gi] = cov[i];
         ha[gi] = accumulate[i];
     }
-    for (int gi = 0; gi < ng; ++gi) {                            // the kernels address a ring through its parent's slot; keep its own slot valid
+    for (int gi = 0; gi < ng; ++gi) {                            // the kernels address a strip through its parent's slot; keep its own slot valid
         const int parent = P->ring_parent[gi];
         if (parent >= 0) { hx[gi] = hx[parent]; hc[gi] = hc[parent]; ha[gi] = 1; }
     }
@@ -1411,14 +1442,11 @@ extern "C" int nsgp_cov_plan_run(nsgp_cov_plan_t* P, const float* const* x, floa
                            128 / bands, hc[sl.group_index], ha[sl.group_index], (const unsigned*)(amax + sl.group_index));
         NSGP_LAUNCH_CHECK();
     }
-    if (P->n_corr > 0) {                                         // correlation form: R from the slabs, C from R, then the ring subtracted
-        hipLaunchKernelGGL(nsgp_cov_corr_reduce_kernel, dim3(P->corr_units), dim3(256), 0, stream, P->d_corr, P->d_layers, (const float*)slabs, ws);
+    if (P->n_corr > 0) {                                         // correlation form: R from the slabs, then C = R laid out over the tap pairs - the strips
+        hipLaunchKernelGGL(nsgp_cov_corr_reduce_kernel, dim3(P->corr_units, 8), dim3(256), 0, stream, P->d_corr, P->d_layers, (const float*)slabs, ws);
         NSGP_LAUNCH_CHECK();
         hipLaunchKernelGGL(nsgp_cov_corr_assemble_kernel, dim3(P->asm_units), dim3(256), 0, stream, corr_ids, pasm, P->n_corr, P->d_layers, ng,
                            (const void*)P->d_dyn[s], (const char*)ws, (const unsigned*)amax);
-        NSGP_LAUNCH_CHECK();
-        hipLaunchKernelGGL(nsgp_cov_group_syrk_kernel, dim3(P->n_tiles_late), dim3(V2L_THREADS), V2_SMEM_BYTES, stream, P->d_tiles + P->n_tiles, P->d_layers, ng,
-                           (const void*)P->d_dyn[s], (const char*)ws, (const unsigned*)amax, slabs);
         NSGP_LAUNCH_CHECK();
     }
     NSGP_HIP(hipEventRecord(P->ev[s], stream));
