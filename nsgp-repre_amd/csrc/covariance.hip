@@ -764,6 +764,7 @@ constexpr int CG_CHUNK = 256 * 64;       // elements per workgroup of the mean /
 constexpr int CG_MAX_STEPS = 600;
 constexpr int CG_CORR_MAX_STEPS = 320;   // correlation tiles: few tiles per layer (26 for C = 256), so shorter ranges also balance the launch
 constexpr int CG_SPLIT_OCTETS = 16;      // l-octets per workgroup of the operand-split launch (4 per wave)
+constexpr int CG_ST_LD = CG_SPLIT_OCTETS * 8 + 4 + 1;      // floats per channel of the staged tile: 128 columns + a halo of 2 either side, odd pitch
 constexpr int CG_ASM_ROWS = 8;           // rows of C per workgroup of the assemble launch
 
 // dyn: [x pointers n][cov pointers n][accumulate flags n]
@@ -830,7 +831,7 @@ __global__ __launch_bounds__(256) void nsgp_cov_group_amax_kernel(const CovGroup
     if (threadIdx.x == 0) atomicMax(amax + li, __float_as_uint(fmaxf(fmaxf(wmax[0], wmax[1]), fmaxf(wmax[2], wmax[3]))));
 }
 
-// one wave = one (64-row block, l-octet) of one layer, as nsgp_cov_im2col_split_kernel
+// one workgroup = one (64-row block, 16 l-octets) of one layer; gather path: one wave per octet as nsgp_cov_im2col_split_kernel
 __global__ __launch_bounds__(256) void nsgp_cov_group_split_kernel(const CovGroupLayer* __restrict__ layers, const int* __restrict__ prefix, int n,
                                                                    const void* __restrict__ dyn, char* __restrict__ ws, const unsigned* __restrict__ amax) {
     const int li = cov_group_find(prefix, n, blockIdx.x);
@@ -843,35 +844,44 @@ __global__ __launch_bounds__(256) void nsgp_cov_group_split_kernel(const CovGrou
     const int d = db * 64 + lane;
     const float scale = f2_scale_from_amax_bits(amax[L.src]);
     if (L.kind == 1) {
-        // correlation operand: row d = (copy j, channel c) holds the flat zero-bordered image shifted by dx = j - 2:
-        // element q = r Wq + s  <-  X[c][r - 2][s + j - 4]
-        const int j = d / L.Cp, c = d - j * L.Cp;
-        const bool live = j < 5 && c < L.cin;
-        const float* __restrict__ img = xm + (long)c * L.H * L.W;
-#pragma unroll
-        for (int i = 0; i < CG_SPLIT_OCTETS / 4; ++i) {
-            const int o = ob * CG_SPLIT_OCTETS + 4 * i + wave;
-            if (o * 8 >= L.Lp) break;                            // uniform per wave
-            const int q0 = o * 8, r = q0 / L.Wq, s0 = q0 - r * L.Wq;      // Wq % 8 == 0: the octet stays in one row
-            const int iy = r - 2, ix0 = s0 + j - 4;
+        // STAGED: row (copy j, channel c) of the correlation operand is the flat zero-bordered image F (element q = r Wq + s <-
+        // X[c][r-2][s-2]) shifted by dx = j - 2, copy_j[q] = F[q + j - 2].  The workgroup owns 64 channels x 128 consecutive q: it
+        // reads F[128 ob - 2 .. 128 ob + 130) of its channels as rows (~512 contiguous bytes per channel), parks them in LDS, and writes
+        // ALL FIVE copies from there (lane = channel: a plane is 1 KiB contiguous).  Against one gather per copy (32 bytes per lane at a
+        // stride of one channel image): 0.58 against 0.65 ms for the launch; the same staging for the 1x1 layers -- whose gather is
+        // 32-byte aligned -- measured slower (0.71) and is not used (profiles/r03/cov_split_study.log).
+        __shared__ float stage[64 * CG_ST_LD];
+        const int cb = db;                                       // channel block (units of a kind-1 layer: Cp / 64 x nob)
+        constexpr int tw = CG_SPLIT_OCTETS * 8 + 4;
+        const float inv_wq = 1.0f / (float)L.Wq;
+        const long chan = (long)L.H * L.W;
+        for (int idx = threadIdx.x; idx < 64 * tw; idx += 256) {
+            const int cl = idx / tw, t = idx - cl * tw, c = cb * 64 + cl;
+            const int q = ob * (CG_SPLIT_OCTETS * 8) - 2 + t;
+            float v = 0.0f;
+            if (c < L.cin && q >= 0) {
+                int r = (int)((float)q * inv_wq);                // q < 2^24: exact after the correction
+                r -= (r * L.Wq > q);
+                r += ((r + 1) * L.Wq <= q);
+                const int iy = r - 2, ix = q - r * L.Wq - 2;
+                if (iy >= 0 && iy < L.H && ix >= 0 && ix < L.W) v = as_global(xm)[c * chan + (long)iy * L.W + ix];
+            }
+            stage[cl * CG_ST_LD + t] = v;
+        }
+        __syncthreads();
+        const int ncopy = 5 + (cb == 0 && L.Dp > 5 * L.Cp ? 1 : 0);      // + the zero block that pads 5 Cp rows to whole 128-row tiles
+        for (int p = wave; p < ncopy * CG_SPLIT_OCTETS; p += 4) {
+            const int j = p / CG_SPLIT_OCTETS, ol = p - j * CG_SPLIT_OCTETS, o = ob * CG_SPLIT_OCTETS + ol;
+            if (o * 8 >= L.Lp) continue;                         // uniform per wave
             f32x4 v[2];
             v[0] = f32x4{0, 0, 0, 0};
             v[1] = f32x4{0, 0, 0, 0};
-            if (live && iy >= 0 && iy < L.H && ix0 + 7 >= 0 && ix0 < L.W) {
-                const float* __restrict__ rowp = img + (long)iy * L.W;
-                if (ix0 >= 0 && ix0 + 7 < L.W) {
-                    const f32x4_u q0v = *(const gf32x4_u*)(rowp + ix0), q1v = *(const gf32x4_u*)(rowp + ix0 + 4);
-                    v[0] = f32x4{q0v[0], q0v[1], q0v[2], q0v[3]};
-                    v[1] = f32x4{q1v[0], q1v[1], q1v[2], q1v[3]};
-                } else {
+            if (j < 5) {
+                const float* src = stage + lane * CG_ST_LD + ol * 8 + j;
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) {
-                        const int ix = ix0 + e;
-                        if (ix >= 0 && ix < L.W) v[e >> 2][e & 3] = as_global(rowp)[ix];
-                    }
-                }
+                for (int e = 0; e < 8; ++e) v[e >> 2][e & 3] = src[e];
             }
-            v2_store_pieces(ws + L.xt_off, d, o, L.Lp, v[0], v[1], scale);
+            v2_store_pieces<true>(ws + L.xt_off, j < 5 ? j * L.Cp + cb * 64 + lane : 5 * L.Cp + lane, o, L.Lp, v[0], v[1], scale);
         }
         return;
     }
@@ -898,7 +908,7 @@ __global__ __launch_bounds__(256) void nsgp_cov_group_split_kernel(const CovGrou
                     if (iy >= 0 && iy < L.H && ix >= 0 && ix < L.W) v[e >> 2][e & 3] = as_global(img)[(long)iy * L.W + ix];
                 }
             }
-            v2_store_pieces(ws + L.xt_off, d, o, L.Lp, v[0], v[1], scale);
+            v2_store_pieces<true>(ws + L.xt_off, d, o, L.Lp, v[0], v[1], scale);
         }
         return;
     }
@@ -915,7 +925,7 @@ __global__ __launch_bounds__(256) void nsgp_cov_group_split_kernel(const CovGrou
             const Patch8 pc = patch8(L.g, inv_wo, o * 8, L.g.L);
             stage8(xm, rowbase, pc, r);
         }
-        v2_store_pieces(ws + L.xt_off, d, o, L.Lp, r[0], r[1], scale);
+        v2_store_pieces<true>(ws + L.xt_off, d, o, L.Lp, r[0], r[1], scale);
     }
 }
 
@@ -1275,7 +1285,7 @@ extern "C" int nsgp_cov_plan_create(nsgp_cov_plan_t** out, const nsgp_cov_geom_t
         const int chunks = (int)((c.n_img + CG_CHUNK - 1) / CG_CHUNK);
         pm.push_back(pm.back() + (c.needs_mean && c.kind != 2 ? chunks : 0));
         pa.push_back(pa.back() + (c.kind == 2 ? 0 : chunks));
-        ps.push_back(ps.back() + ((c.Lp / 8 + CG_SPLIT_OCTETS - 1) / CG_SPLIT_OCTETS) * (c.Dp / 64));
+        ps.push_back(ps.back() + ((c.Lp / 8 + CG_SPLIT_OCTETS - 1) / CG_SPLIT_OCTETS) * ((c.kind == 1 ? c.Cp : c.Dp) / 64));      // kind 1: a workgroup writes all five copies of its channels
         if (c.kind == 1) {
             const CorrShape s = corr_shape(c.cin, c.H, c.W);
             int steps;

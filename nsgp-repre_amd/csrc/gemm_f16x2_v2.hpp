@@ -267,12 +267,18 @@ __device__ __forceinline__ void gemm_tile_f16x2_v2l(const void* __restrict__ Asp
 
 // ---- operand preparation ------------------------------------------------------------------------------------------------
 // One 16-byte piece pair: 8 consecutive k of one row, scaled, split and stored to its two planes.
+template <bool NT = false>
 __device__ __forceinline__ void v2_store_pieces(void* __restrict__ dst, int row, int octet, int K, const f32x4 lo, const f32x4 hi, float scale) {
     h16x8 p0, p1;
     f2_split(lo, hi, scale, p0, p1);
     char* base = static_cast<char*>(dst) + v2_plane_offset(row >> 6, octet, 0, K) + (row & 63) * 16;
-    *(g_h16x8*)(base) = p0;
-    *(g_h16x8*)(base + V2_PLANE) = p1;
+    if constexpr (NT) {      // a stream written once and read back from HBM by a later launch: keep it out of the way of what L2 holds
+        __builtin_nontemporal_store(p0, (g_h16x8*)(base));
+        __builtin_nontemporal_store(p1, (g_h16x8*)(base + V2_PLANE));
+    } else {
+        *(g_h16x8*)(base) = p0;
+        *(g_h16x8*)(base + V2_PLANE) = p1;
+    }
 }
 
 // Stand-alone row split of a [rows x K] fp32 matrix (rows % 8 == 0, K % 8 == 0): one workgroup per band of 8 rows finds
