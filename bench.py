@@ -175,11 +175,16 @@ def once_per_task_units(N, dev):
             "reference_flops": ref_flops, "tflops_by_reference_flops": ref_flops / (ms * 1e-3) / 1e12,
             "roofline": {"bound": "mfma", "achieved": up / (ms * 1e-3) / 1e12, "peak": PEAK_16BIT_MATRIX_TFLOPS, "unit": "TFLOP/s",
                          "frac": up / (ms * 1e-3) / 1e12 / PEAK_16BIT_MATRIX_TFLOPS,
-                         "executed_mfma_utilisation": 3.0 * up / (ms * 1e-3) / 1e12 / PEAK_16BIT_MATRIX_TFLOPS,
-                         "note": "algorithmic = the upper triangles (diagonal blocks whole) of the grouped layers, sum L D (D + 128) FLOP, over the WHOLE "
-                                 "hooked forward (mean / amax / operand split / SYRK + the stem at hook time); three fp16 MFMA products per fp32-equivalent product"},
-            "note": "one hooked forward at 800x1344 (fp32 activations), grouped pass: all layers with D % 64 == 0 in one plan run (five launches, one tile "
-                    "table, no split-K, no reduce), the 7x7 stem at hook time on a side stream; ms_hook_time_* = round 2's per-layer launches"}
+                         "executed_mfma_flops": st["tile_steps"] * (256 * 128 * 32 * 2 * 3.0),
+                         "executed_mfma_utilisation": st["tile_steps"] * (256 * 128 * 32 * 2 * 3.0) / (ms * 1e-3) / 1e12 / PEAK_16BIT_MATRIX_TFLOPS,
+                         "note": "algorithmic = what the reference's X^T X needs: the upper triangles (diagonal blocks whole) of the grouped layers, sum L D (D + 128) FLOP, "
+                                 "over the WHOLE hooked forward (mean / amax / operand split / SYRK / assemble + the stem at hook time).  executed = the k32 steps of "
+                                 "256 x 128 tiles the SYRK launch runs x three fp16 MFMA products per fp32-equivalent product: the 3x3 / stride 1 / padding 1 layers "
+                                 "on the large maps run in the correlation form (13 shifted C x C products instead of 40.5 blocks), so frac can exceed what the "
+                                 "tile's own rate would give on the plain upper triangle"},
+            "note": "one hooked forward at 800x1344 (fp32 activations), grouped pass: all layers with D % 64 == 0 in one plan run (mean, amax, operand split, "
+                    "one SYRK tile table, ordered reduces of the long contractions, R reduce + assemble of the correlation-form layers), the 7x7 stem at hook "
+                    "time on a side stream; ms_hook_time_* = round 2's per-layer launches (im2col form)"}
     torch.cuda.empty_cache()
     # a5 -> a7: spectra and projectors of all 50 projected layers from SURVEY 8d's seeded covariances (runner:635-662)
     import nsgp_oracle as O

@@ -1064,23 +1064,34 @@ __global__ __launch_bounds__(256) void nsgp_cov_corr_assemble_kernel(const int* 
     gfloat* cov = as_global(cg_cov(dyn, n, L.src));
     const bool accumulate = cg_acc(dyn, n, L.src) != 0;
     const int d1_0 = (blockIdx.x - prefix[k]) * CG_ASM_ROWS;
+    const int nrows = min(CG_ASM_ROWS, D - d1_0);
+    const long plane = (long)L.Cp * L.Cp;
     for (int d2 = threadIdx.x; d2 < D; d2 += 256) {
+        // the column's share of every index, once: R[(ky2-ky1+2)*5 + kx2-kx1+2][c1][c2] = R[ky2*5 + kx2][.][c2] shifted by the row's uniform part
         const int c2 = d2 / 9, t2 = d2 - 9 * c2, ky2 = t2 / 3, kx2 = t2 - 3 * ky2;
-#pragma unroll 4
+        const long r_col = (long)(ky2 * 5 + kx2) * plane + c2;
+        const int sx_col = 3 * c2 + kx2, sy_col = 3 * c2 + ky2;
+        float old[CG_ASM_ROWS], val[CG_ASM_ROWS];
+#pragma unroll
         for (int row = 0; row < CG_ASM_ROWS; ++row) {
-            const int d1 = d1_0 + row;                         // uniform
-            if (d1 >= D) break;
-            const int c1 = d1 / 9, t1 = d1 - 9 * c1, ky1 = t1 / 3, kx1 = t1 - 3 * ky1;
-            float v = R[(((long)(ky2 - ky1 + 2) * 5 + (kx2 - kx1 + 2)) * L.Cp + c1) * L.Cp + c2] * unscale;
-            float sub = 0.0f;                                  // fixed order, symmetric operands: (d1,d2) and (d2,d1) subtract the same number
-            if (ky1 == 2 && ky2 == 2) sub += s_top[(long)(3 * c1 + kx1) * ld3 + 3 * c2 + kx2];
-            if (ky1 == 0 && ky2 == 0) sub += s_bot[(long)(3 * c1 + kx1) * ld3 + 3 * c2 + kx2];
-            if (kx1 == 2 && kx2 == 2) sub += s_lft[(long)(3 * c1 + ky1) * ld3 + 3 * c2 + ky2];
-            if (kx1 == 0 && kx2 == 0) sub += s_rgt[(long)(3 * c1 + ky1) * ld3 + 3 * c2 + ky2];
-            v -= sub;
-            const long o = (long)d1 * D + d2;
-            cov[o] = accumulate ? (cov[o] + v) : v;
+            old[row] = 0.0f;
+            val[row] = 0.0f;
+            if (row < nrows) {
+                const int d1 = d1_0 + row;                     // uniform
+                const int c1 = d1 / 9, t1 = d1 - 9 * c1, ky1 = t1 / 3, kx1 = t1 - 3 * ky1;
+                float v = R[r_col + (long)((2 - ky1) * 5 + (2 - kx1)) * plane + (long)c1 * L.Cp] * unscale;
+                float sub = 0.0f;                              // fixed order, symmetric operands: (d1,d2) and (d2,d1) subtract the same number
+                if (ky1 == 2 && ky2 == 2) sub += s_top[(long)(3 * c1 + kx1) * ld3 + sx_col];
+                if (ky1 == 0 && ky2 == 0) sub += s_bot[(long)(3 * c1 + kx1) * ld3 + sx_col];
+                if (kx1 == 2 && kx2 == 2) sub += s_lft[(long)(3 * c1 + ky1) * ld3 + sy_col];
+                if (kx1 == 0 && kx2 == 0) sub += s_rgt[(long)(3 * c1 + ky1) * ld3 + sy_col];
+                val[row] = v - sub;
+                if (accumulate) old[row] = __builtin_nontemporal_load(cov + (long)d1 * D + d2);      // C is touched once per forward: streamed past L2
+            }
         }
+#pragma unroll
+        for (int row = 0; row < CG_ASM_ROWS; ++row)
+            if (row < nrows) __builtin_nontemporal_store(accumulate ? old[row] + val[row] : val[row], cov + (long)(d1_0 + row) * D + d2);
     }
 }
 
