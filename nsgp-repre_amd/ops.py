@@ -167,7 +167,8 @@ def cov_workspace_bytes(cin, H, W, kernel_size, stride, padding) -> int:
 
 
 class CovGroupPlan:
-    """All hooked convolutions of ONE forward in five launches (``nsgp_cov_plan_*``, csrc/covariance.hip "grouped pass").
+    """All hooked convolutions of ONE forward in a handful of launches (``nsgp_cov_plan_*``, csrc/covariance.hip "grouped pass";
+    the 3x3 / stride 1 / padding 1 layers on large maps in the correlation form: ``n_correlation_form``, ``cov_set_corr_mode``).
 
     ``geoms``: one ``(batch, cin, h, w, kernel_size, stride, padding)`` per layer.  ``routes[i]`` says whether layer i rides in the
     grouped launches (True) or has to go through ``cov_accumulate_conv2d`` (False: D not a multiple of 64).  ``run(xs, covs)``

@@ -132,7 +132,7 @@ class CovarianceCollector:
         self._streams = CovarianceStreams(n_streams) if n_streams > 1 else None
         #: GROUPED pass (default on the GPU): the hooks of the convolutions whose D = Cin*kh*kw is a multiple of 64 only stash their
         #: input; ``flush()`` -- called by ``cal_fea_in`` after every forward, by ``join()`` and ``remove()`` -- accumulates all of
-        #: them in five launches (``ops.CovGroupPlan``: one tile table over all layers, no split-K, no reduce).  The other layers
+        #: them in a handful of launches (``ops.CovGroupPlan``: one tile table over all layers, no split-K; 3x3 layers in the correlation form).  The other layers
         #: (the 7x7 stem, Linear) are accumulated at hook time as before, on the side streams.  False = every layer at hook time.
         self.grouped = grouped
         self._pending = []
