@@ -322,15 +322,47 @@ def repre_step(N, dev, K, split, reps=30):
     # figure (a synchronisation before every pass: launch latency and a cold clock on top) is reported beside it
     stream_ms, host_ms = steady(True, False)
     iso_ms, fused_fwd_ms = timed(True, False), timed(True, False, backward=False)
+
+    def graph_replay_ms(n=200):
+        """The same pass captured once in a HIP graph (torch.cuda.graph: the 11 launches of the C calls are issued on the capturing
+        stream) and replayed n times: no Python between the launches, i.e. the GPU time of the pass whatever the host's speed."""
+        try:
+            side = torch.cuda.Stream(device=dev)
+            side.wait_stream(torch.cuda.current_stream(dev))
+            with torch.cuda.stream(side):
+                for _ in range(3):
+                    one(True, False)
+            torch.cuda.current_stream(dev).wait_stream(side)
+            torch.cuda.synchronize()
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                one(True, False)
+            for _ in range(20):
+                graph.replay()
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(n):
+                graph.replay()
+            e1.record()
+            torch.cuda.synchronize()
+            ms = e0.elapsed_time(e1) / n
+            del graph
+            return ms
+        except Exception as exc:      # a capture the runtime refuses is a missing number, not a failed bench
+            torch.cuda.synchronize()
+            return f"not captured: {type(exc).__name__}: {str(exc)[:120]}"
+    graph_ms = graph_replay_ms()
     module_ms, _ = steady(False, False)
     bf16_ms, _ = steady(False, True, n=20)
     flops = 2.0 * 2.0 * K * (fin * hid + hid * hid + C_ * hid)
     nbytes = 4.0 * (2 * hid * fin + 2 * K * fin + 2 * hid * hid + 2 * C_ * hid)
     rp.fused_replay = True
     return {"K": K, "task_split": list(split), "kept_class_columns": C_, "repre_step_ms": stream_ms, "host_issue_ms": host_ms,
-            "isolated_pass_ms": iso_ms, "isolated_forward_only_ms": fused_fwd_ms, "module_path_fp32_ms": module_ms, "module_path_bf16_autocast_ms": bf16_ms,
-            "timing": "HIP events around 200 passes back to back after 20 warm-ups (head.zero_grad + forward + backward each); isolated = median of 30 "
-                      "passes with a synchronisation before each; module paths: the same steady-state protocol",
+            "graph_replay_ms": graph_ms, "isolated_pass_ms": iso_ms, "isolated_forward_only_ms": fused_fwd_ms, "module_path_fp32_ms": module_ms, "module_path_bf16_autocast_ms": bf16_ms,
+            "timing": "HIP events around 200 passes back to back after 20 warm-ups (head.zero_grad + forward + backward each): the pass is host-bound, so "
+                      "repre_step_ms follows the box's host speed (host_issue_ms beside it); graph_replay_ms = the same pass captured in a HIP graph and "
+                      "replayed 200 times = its GPU time; isolated = median of 30 passes with a synchronisation before each; module paths: the steady-state protocol",
             "launches": "forward: skinny split-K GEMM + slab reduce (x2), class scores + row CE terms, mean = 6; backward: CE, dZ2 (+ class-head gradients), "
                         "skinny GEMM, dZ1, grouped weight-gradient GEMM = 5 (csrc/replay_head.hip)",
             "roofline": {"algorithmic_flops": flops, "algorithmic_bytes": nbytes,
