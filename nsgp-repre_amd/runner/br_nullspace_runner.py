@@ -31,7 +31,8 @@ class NullSpaceTaskMixin:
                         previous_dir: Optional[str] = None, ckpt_keywords: str = "best",
                         ignore_keys: Optional[Sequence[str]] = None, offset: float = 0.0, reserve_per_class: int = 0,
                         is_trained: bool = False, fea_in_load_path: Optional[str] = None,
-                        rr_thresh: Optional[Sequence[float]] = None):
+                        rr_thresh: Optional[Sequence[float]] = None, cov_grouped: bool = True, cov_streams: int = 4):
+        self.cov_grouped, self.cov_streams = bool(cov_grouped), int(cov_streams)      # how cal_fea_in issues the covariance launches
         self.task_id = task_id if task_id is not None else 1
         self.task_split = train_task_split
         self.previous_dir = previous_dir if self.task_id != 1 else None
@@ -153,7 +154,8 @@ class NullSpaceTaskMixin:
     # -- end of task t --------------------------------------------------------------------------
     def cal_fea_in(self, model, batches: Iterable, forward: Optional[Callable] = None):
         return NS.cal_fea_in(model, batches, self.ignore_keys, self.fea_in_save_path,
-                             self.fea_in_load_path if self.task_id != 1 else None, self.task_id, forward)
+                             self.fea_in_load_path if self.task_id != 1 else None, self.task_id, forward,
+                             grouped=self.cov_grouped, n_streams=self.cov_streams)
 
     def cal_rois(self, model, batches: Iterable, forward: Optional[Callable] = None, num_classes: int = 20):
         prev = osp.join(self.previous_dir, "rois_etc.pth") if (self.task_id != 1 and self.previous_dir) else None
@@ -172,7 +174,7 @@ if HAVE_MMENGINE:  # pragma: no cover - exercised only where mmengine is install
             runner.init_task_state(runner.work_dir, cfg.get("task_id"), cfg.get("train_task_split"),
                                    cfg.get("previous_dir"), cfg.get("ckpt_keywords", "best"), cfg.get("ignore_keys"),
                                    cfg.get("offset"), cfg.get("reserve_per_class"), cfg.get("is_trained"),
-                                   cfg.get("fea_in_load_path"), cfg.get("rr_thresh"))
+                                   cfg.get("fea_in_load_path"), cfg.get("rr_thresh"), cfg.get("cov_grouped", True), cfg.get("cov_streams", 4))
             return runner
 
         def train(self):

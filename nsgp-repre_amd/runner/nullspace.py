@@ -241,11 +241,14 @@ class CovarianceCollector:
 
 @torch.no_grad()
 def cal_fea_in(model: nn.Module, batches: Iterable, ignore_keys: Sequence[str], save_path: Optional[str] = None,
-               previous_path: Optional[str] = None, task_id: int = 1, forward=None) -> Dict[str, torch.Tensor]:
+               previous_path: Optional[str] = None, task_id: int = 1, forward=None, grouped: bool = True,
+               n_streams: int = 4) -> Dict[str, torch.Tensor]:
     """One hooked pass over ``batches`` in eval mode (runner:705-763).  ``forward(model, batch)`` runs
     one batch through the model (the reference calls ``model(inputs, data_samples, mode='nullspace')``
-    after ``data_preprocessor``); the default calls ``model(batch)``."""
-    collector = CovarianceCollector(model, ignore_keys).register()
+    after ``data_preprocessor``); the default calls ``model(batch)``.  ``grouped`` / ``n_streams``: see ``CovarianceCollector``
+    (``grouped=False, n_streams=1`` is the reference's own order of operations: every hook accumulates on the current stream
+    before the next layer runs -- the setting for a model that modifies a convolution's input in place)."""
+    collector = CovarianceCollector(model, ignore_keys, n_streams=n_streams, grouped=grouped).register()
     net = unwrap(model)
     was_training = net.training
     net.eval()
