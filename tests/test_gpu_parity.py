@@ -463,6 +463,39 @@ def test_grouped_covariance_correlation_form(N, dev):
     plan.close()
 
 
+def test_correlation_form_on_random_geometries(N, dev):
+    """Seeded sweep: channels 64 ... 448 (every remainder of the 256-channel row tiles), maps 4 ... 40 on a side (widths on both sides of a
+    multiple of 32 after the + 4 halo), batch 1 ... 3 -- the forced correlation form against the im2col form of the same plan (both within
+    the gate of the oracle) and bit-symmetric."""
+    from nsgp_repre_amd import ops
+    rs = np.random.default_rng(77)
+    k3 = ((3, 3), (1, 1), (1, 1))
+    geoms = []
+    for c in (64, 128, 192, 256, 320, 384, 448):
+        h, w = int(rs.integers(4, 41)), int(rs.choice([4, 12, 27, 28, 29, 40, 59, 60, 61]))
+        if h * w < 32:
+            h = 8
+        geoms.append((int(rs.integers(1, 4)), c, h, w) + k3)
+    g = torch.Generator().manual_seed(78)
+    xs = [torch.randn(b, c, h, w, generator=g).abs() for b, c, h, w, *_ in geoms]
+    xd = [x.to(dev) for x in xs]
+    res = {}
+    for mode in (2, 0):
+        prev = ops.cov_set_corr_mode(mode)
+        try:
+            plan = ops.CovGroupPlan(geoms, dev)
+        finally:
+            ops.cov_set_corr_mode(prev)
+        assert plan.n_correlation_form == (len(geoms) if mode == 2 else 0)
+        res[mode] = plan.run(xd, [None] * len(geoms))
+        torch.cuda.synchronize()
+        plan.close()
+    for i, (x, gm) in enumerate(zip(xs, geoms)):
+        ref = O.cov_conv2d(x, gm[4], gm[5], gm[6])
+        assert _row_rel(res[2][i], ref) <= REL and _row_rel(res[0][i], ref) <= REL, (gm, _row_rel(res[2][i], ref), _row_rel(res[0][i], ref))
+        assert torch.equal(res[2][i], res[2][i].t().contiguous()), gm
+
+
 @pytest.mark.parametrize("mode", [0, 2, 3, 4])
 @pytest.mark.parametrize("name", list(_TRUE_SIZE))
 def test_covariance_at_true_size(N, dev, name, mode):
