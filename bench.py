@@ -792,16 +792,18 @@ def hot_path_only(N, dev, args, cache):
                                                                                                        "lowrank_apply"), opt.profile_detail())),
                                                        "note": "optimizer.mutate_grad = False: p.grad is left as backward() wrote it"}
         opt.mutate_grad = True
-    # a MIXED step: a layer whose elbow removes more than 128 directions falls back to the dense GEMM (logged by set_basis); here the three
-    # 4608-wide layers get 160 removed directions, so 47 layers run the low-rank launches and 3 the dense fp16-split kernel
+    # MIXED steps: the three 4608-wide layers with (a) 160 removed directions -- the wide rank class (129 .. 256: its own fused + apply launches
+    # beside the common ones, all 50 layers on the low-rank form) -- and (b) 300 -- beyond the low-rank form: those three fall back to the dense
+    # fp16-split GEMM (logged by set_basis), 47 stay on the low-rank launches
     if not args.hot_path_only:
         wide = [n for n, shape, proj in table if proj and shape[1] * shape[2] * shape[3] == 4608]
-        for n in wide:
-            opt.set_basis(n, cache[4608][0], 160)
-        _ms3, u3, g3 = timed(args.steps)
-        out["low_rank_form"]["mixed_step_3_layers_above_128_directions"] = {
-            "nsgp_step_ms": u3 + g3, "layers_on_low_rank": f"{opt.lowrank_stats()[0]}/{len([1 for _, _, pr in table if pr])}", "dense_tiles_f16x2": opt.tile_counts()[2],
-            "launch_ms": dict(zip(("update", "update_lr_fused_t", "dense_gemm", "lowrank_reduce", "lowrank_apply"), opt.profile_detail()))}
+        for r_wide, key in ((160, "mixed_step_3_layers_at_160_directions_wide_rank_class"), (300, "mixed_step_3_layers_at_300_directions_dense_fallback")):
+            for n in wide:
+                opt.set_basis(n, cache[4608][0], r_wide)
+            _ms3, u3, g3 = timed(args.steps)
+            out["low_rank_form"][key] = {
+                "nsgp_step_ms": u3 + g3, "layers_on_low_rank": f"{opt.lowrank_stats()[0]}/{len([1 for _, _, pr in table if pr])}", "dense_tiles_f16x2": opt.tile_counts()[2],
+                "launch_ms": dict(zip(("update", "update_lr_fused_t", "dense_gemm", "lowrank_reduce", "lowrank_apply"), opt.profile_detail()))}
         for n in wide:
             opt.set_basis(n, cache[4608][0], cache[4608][1])
     # ---- the dense GEMM on every MFMA path, with the SAME projectors (what externally assigned projectors run on)

@@ -444,7 +444,7 @@ __device__ __forceinline__ void lowrank_source(const LayerDev& L, const DynBlock
 
 constexpr int LRA_COLS = 256;        // columns of one apply workgroup
 static_assert(LRA_COLS == 256, "the apply kernel gives each of its four waves at most two 32-column blocks");
-constexpr int LR_MAX_RANK = 128;
+constexpr int LR_MAX_RANK = 256;       // rank classes 32 / 64 / 128 share the launches; 129 .. 256 removed directions (rpad = 256) get their own pair (NB = 2 / MAXR = 256)
 constexpr int LR_TILE_LD = 36;       // floats per row of a [32 x 32] LDS tile: 144 B, so that 8 lanes reading 16 B of 8 consecutive rows cover all 32 banks
 constexpr int LR_TILE = 32 * LR_TILE_LD;
 
@@ -488,7 +488,9 @@ __device__ __forceinline__ f32x4 lds_get4(const float* tile, int off) { return *
 // (nsgp_lr_reduce_kernel sums the slabs in range order): deterministic.
 // (First form: each wave contracted its own groups with ALL column blocks -- 16 NJ accumulator registers, a launch per rank
 // class, the U loads of blocks 1.. on the dependent chain: 78 us for each of the two wide classes of R-50-FPN.)
-template <int OPT>
+// NB = 2: the WIDE rank class (129 .. 256 removed directions, rpad = 256): every wave keeps TWO 32-column blocks of U (wave and wave + 4) and
+// contracts all four tiles of a round with both -- 32 accumulator registers, 128 MFMAs per round; its layers run in their own launch.
+template <int OPT, int NB>
 __global__ __launch_bounds__(256) void nsgp_update_lr_kernel(const TileDev* __restrict__ units, const LayerDev* __restrict__ layers,
                                                              const TensorDev* __restrict__ tensors, const DynBlock* __restrict__ dyn,
                                                              int n_units, const ChunkDev* __restrict__ plain_chunks) {
@@ -510,7 +512,7 @@ __global__ __launch_bounds__(256) void nsgp_update_lr_kernel(const TileDev* __re
     const int ngroups = L.cols >> 5;               // groups of 32 k = one 128-byte line per row
     const int per = (ngroups + L.nsplit - 1) / L.nsplit;
     const int g0 = min(ngroups, t.pad * per), g1 = min(ngroups, g0 + per);
-    const int nj = L.rpad >> 5;                    // 1, 2 or 4
+    const int nj = NB == 2 ? 4 : (L.rpad >> 5);    // 1, 2 or 4 column blocks across the waves (wide: 4, twice)
     const int jb = wave & (nj - 1), sub = wave / nj, tstride = 4 / nj;
     // what the projection reads as its A operand, and whether the mutated gradient must be stored (as in nsgp_update_kernel)
     const bool a_is_buf = (OPT == NSGP_OPT_SGD) && h.momentum != 0.0f && !h.nesterov;
@@ -521,11 +523,13 @@ __global__ __launch_bounds__(256) void nsgp_update_lr_kernel(const TileDev* __re
     const float scale = (OPT == NSGP_OPT_SGD) ? -h.lr : 1.0f;
     const long rowbase = (long)(t.m0 + r8) * L.cols + 4 * ch;             // + 8 it rows, + 32 g columns
     const long r8s = 8L * L.cols;
-    const float* ub = L.ukq + ((long)hh * L.rpad + jb * 32 + i) * 4;      // quad 8 g + 2 st + hh, column 32 jb + i
+    const float* ub = L.ukq + ((long)hh * L.rpad + jb * 32 + i) * 4;      // quad 8 g + 2 st + hh, column 32 jb + i (second block of a wide layer: + 128 columns)
     const long qs = 2L * L.rpad * 4, qg = 8L * L.rpad * 4;                // floats per k8 step, per group
-    f32x16 acc;
+    f32x16 acc[NB];
 #pragma unroll
-    for (int v = 0; v < 16; ++v) acc[v] = 0.0f;
+    for (int b = 0; b < NB; ++b)
+#pragma unroll
+        for (int v = 0; v < 16; ++v) acc[b][v] = 0.0f;
     // (Measured and not kept: requesting the NEXT round's stream before the barrier and the matrix work -- in front of or behind
     // the U fragments, 8 or 16 groups per workgroup -- 128-134 us on the R-50 table either way, at 134 instead of 112 VGPRs: vmcnt
     // retires in order, so every fragment wait inside the consume phase waits for the prefetched stream as well.)
@@ -577,13 +581,15 @@ __global__ __launch_bounds__(256) void nsgp_update_lr_kernel(const TileDev* __re
             for (int it = 0; it < 4; ++it) lds_put4(tiles + wave * LR_TILE, (r8 + 8 * it) * LR_TILE_LD + 4 * ch, a4[it]);
         }
         // ---- consume: my column block of U against nj of the round's tiles
-        f32x4 bx[2][4];                            // the fragments of tile x + 1 are requested while tile x is contracted
+        f32x4 bx[2][NB][4];                        // the fragments of tile x + 1 are requested while tile x is contracted
         auto load_b = [&](int x, auto set_) {
             constexpr int set = decltype(set_)::value;
             const int gx = gb + sub + tstride * x;
             if (x < nj && gx < g1) {
 #pragma unroll
-                for (int st = 0; st < 4; ++st) bx[set][st] = *(const gf32x4*)(ub + gx * qg + st * qs);
+                for (int b = 0; b < NB; ++b)
+#pragma unroll
+                    for (int st = 0; st < 4; ++st) bx[set][b][st] = *(const gf32x4*)(ub + gx * qg + st * qs + b * 512);
             }
         };
         auto contract = [&](int x, auto set_) {
@@ -594,9 +600,11 @@ __global__ __launch_bounds__(256) void nsgp_update_lr_kernel(const TileDev* __re
 #pragma unroll
                 for (int st = 0; st < 4; ++st) f[st] = lds_get4(tiles + tx * LR_TILE, i * LR_TILE_LD + 4 * (2 * st + hh));   // k = 32 g + 8 st + 4 hh + e
 #pragma unroll
-                for (int st = 0; st < 4; ++st)
+                for (int b = 0; b < NB; ++b)
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(f[st][e], bx[set][st][e], acc, 0, 0, 0);
+                    for (int st = 0; st < 4; ++st)
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) acc[b] = __builtin_amdgcn_mfma_f32_32x32x2f32(f[st][e], bx[set][b][st][e], acc[b], 0, 0, 0);
             }
         };
         load_b(0, IC<0>{});
@@ -610,18 +618,21 @@ __global__ __launch_bounds__(256) void nsgp_update_lr_kernel(const TileDev* __re
         contract(3, IC<1>{});
     }
     // the waves that share a column block (wave = sub * nj + jb), summed in wave order (deterministic)
-    __syncthreads();                               // every wave is done with the tiles: the buffer becomes four partial blocks
     float* mine = lds + wave * 1024;
-#pragma unroll
-    for (int v = 0; v < 16; ++v) mine[acc_row(v, lane) * 32 + i] = acc[v];
-    __syncthreads();
     float* dst = (L.nsplit > 1) ? L.slabs + (long)t.pad * L.rows * L.rpad : L.T;
     const float osc = (L.nsplit > 1) ? 1.0f : scale;
-    for (int idx = threadIdx.x; idx < nj * 1024; idx += 256) {
-        const int j = idx >> 10, e = idx & 1023;                  // column block, element (row e >> 5, column e & 31)
-        float sum = lds[j * 1024 + e];
-        for (int k = 1; k < tstride; ++k) sum += lds[(k * nj + j) * 1024 + e];
-        as_global(dst)[(long)(t.m0 + (e >> 5)) * L.rpad + j * 32 + (e & 31)] = osc * sum;
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+        __syncthreads();                           // every wave is done with the tiles (with the previous block's partials): the buffer becomes four partial blocks
+#pragma unroll
+        for (int v = 0; v < 16; ++v) mine[acc_row(v, lane) * 32 + i] = acc[b][v];
+        __syncthreads();
+        for (int idx = threadIdx.x; idx < nj * 1024; idx += 256) {
+            const int j = idx >> 10, e = idx & 1023;              // column block, element (row e >> 5, column e & 31)
+            float sum = lds[j * 1024 + e];
+            for (int k = 1; k < tstride; ++k) sum += lds[(k * nj + j) * 1024 + e];
+            as_global(dst)[(long)(t.m0 + (e >> 5)) * L.rpad + 128 * b + j * 32 + (e & 31)] = osc * sum;
+        }
     }
 }
 
@@ -644,10 +655,10 @@ __global__ __launch_bounds__(256) void nsgp_lr_reduce_kernel(const ChunkDev* __r
     *(gf32x4*)(L.T + i) = scale * sum;
 }
 
-template <int OPT>
+template <int OPT, int MAXR>
 __global__ __launch_bounds__(256) void nsgp_lr_apply_kernel(const TileDev* __restrict__ units, const LayerDev* __restrict__ layers,
                                                             const DynBlock* __restrict__ dyn) {
-    __shared__ __attribute__((aligned(16))) float t_lds[32 * (LR_MAX_RANK + 4)];      // T[m0 .. m0+32][rpad], rows padded by 4 floats
+    __shared__ __attribute__((aligned(16))) float t_lds[32 * (MAXR + 4)];             // T[m0 .. m0+32][rpad], rows padded by 4 floats (MAXR = 256: the wide class's launch)
     __shared__ __attribute__((aligned(16))) float w_lds[4 * LR_TILE];                  // per wave: a U chunk, then the output block
     const TileDev t = units[blockIdx.x];           // m0, n0, pad = columns of this workgroup (<= 256, a multiple of 32)
     const LayerDev L = layers[t.layer];
@@ -755,7 +766,7 @@ struct nsgp_plan {
     // cache blocking of the low-rank launches: the layers are cut into groups whose (update, p) working set fits the 256 MB
     // Infinity Cache, and fused -> reduce -> apply run group by group, so that the apply launch's re-read of the update and of p
     // (8 of its 12 bytes per element) is served by the memory-side cache instead of HBM.  Offsets / counts into d_tiles, d_chunks_lr.
-    struct LrGroup { int lr1_off, lr1_n, lr2_off, lr2_n, chunk_off, chunk_n; };
+    struct LrGroup { int lr1_off, lr1_n, lr2_off, lr2_n, chunk_off, chunk_n, wide; };      // wide: the rpad = 256 layers (their own kernels)
     std::vector<LrGroup> lr_groups;
     ChunkDev* d_chunks_lr = nullptr;
     double lowrank_flops = 0;
@@ -789,7 +800,7 @@ static bool tensor_lowrank(const nsgp_tensor_t& t) {
            aligned16(t.basis) && aligned16(t.basis_rows) && t.proj && aligned16(t.param) && aligned16(t.state0) && aligned16(t.state1) &&
            aligned16(t.state2);
 }
-static int lr_rpad(int rank) { return rank <= 32 ? 32 : (rank <= 64 ? 64 : 128); }   // U's padded width: 32, 64 or 128 columns
+static int lr_rpad(int rank) { return rank <= 32 ? 32 : (rank <= 64 ? 64 : (rank <= 128 ? 128 : 256)); }   // U's padded width: 32, 64, 128 or 256 columns
 // K ranges of a low-rank layer in the fused update + T launch: ~8 groups of 32 columns per workgroup (2 per wave), at most 16
 // ranges.  (32 groups per workgroup left the two wide rank classes of R-50-FPN with 240 workgroups each -- under one per CU --
 // and 78 us apiece; the slabs this costs are a few MB.)
@@ -1027,10 +1038,11 @@ extern "C" int nsgp_plan_create(nsgp_plan_t** out, const nsgp_tensor_t* tensors,
         const int G = std::max(1, std::min(std::min(16, g_lr_groups), (int)std::max<size_t>(1, lo.size())));
         double total_el = 0;
         for (int li : lo) total_el += (double)ld[li].rows * ld[li].cols;
-        std::vector<std::vector<int>> groups(G);
+        std::vector<std::vector<int>> groups(G + 1);      // the last group: the wide rank class (rpad = 256), launched with its own kernels
         {
             double seen = 0;
             for (int li : lo) {
+                if (ld[li].rpad > 128) { groups[G].push_back(li); continue; }
                 const int gi = std::min(G - 1, (int)(seen * G / std::max(total_el, 1.0)));
                 groups[gi].push_back(li);
                 seen += (double)ld[li].rows * ld[li].cols;
@@ -1038,7 +1050,7 @@ extern "C" int nsgp_plan_create(nsgp_plan_t** out, const nsgp_tensor_t* tensors,
         }
         for (auto& grp : groups) {
             if (grp.empty()) continue;
-            nsgp_plan::LrGroup rec{(int)lr1.size(), 0, (int)lr2.size(), 0, (int)lr_chunks.size(), 0};
+            nsgp_plan::LrGroup rec{(int)lr1.size(), 0, (int)lr2.size(), 0, (int)lr_chunks.size(), 0, &grp == &groups.back() ? 1 : 0};
             {
                 std::vector<TileDev> q[8], part;
                 for (int li : grp)
@@ -1274,12 +1286,12 @@ extern "C" int nsgp_plan_step(nsgp_plan_t* P, float* const* grads, const nsgp_hy
     const TileDev* t2 = t1 + P->n_tiles_lr1;
     for (const nsgp_plan::LrGroup& g : P->lr_groups) {
         const int extra = (&g == &P->lr_groups.front()) ? P->n_chunks_plain : 0;      // the un-projected tensors ride in the first group's launch
-        if (P->optimizer == NSGP_OPT_SGD)
-            hipLaunchKernelGGL(nsgp_update_lr_kernel<NSGP_OPT_SGD>, dim3(g.lr1_n + extra), dim3(256), 0, stream, t1 + g.lr1_off, P->d_layers, P->d_tensors, d,
-                               g.lr1_n, P->d_chunks_plain);
-        else
-            hipLaunchKernelGGL(nsgp_update_lr_kernel<NSGP_OPT_ADAM>, dim3(g.lr1_n + extra), dim3(256), 0, stream, t1 + g.lr1_off, P->d_layers, P->d_tensors, d,
-                               g.lr1_n, P->d_chunks_plain);
+#define LR_FUSED(OPTV, NBV)                                                                                                                      \
+    hipLaunchKernelGGL((nsgp_update_lr_kernel<OPTV, NBV>), dim3(g.lr1_n + extra), dim3(256), 0, stream, t1 + g.lr1_off, P->d_layers, P->d_tensors, d, \
+                       g.lr1_n, P->d_chunks_plain)
+        if (P->optimizer == NSGP_OPT_SGD) { if (g.wide) LR_FUSED(NSGP_OPT_SGD, 2); else LR_FUSED(NSGP_OPT_SGD, 1); }
+        else { if (g.wide) LR_FUSED(NSGP_OPT_ADAM, 2); else LR_FUSED(NSGP_OPT_ADAM, 1); }
+#undef LR_FUSED
         NSGP_LAUNCH_CHECK();
         if (prof) NSGP_HIP(hipEventRecord(pe[ei++], stream));
         if (g.chunk_n > 0) {
@@ -1287,10 +1299,10 @@ extern "C" int nsgp_plan_step(nsgp_plan_t* P, float* const* grads, const nsgp_hy
             NSGP_LAUNCH_CHECK();
         }
         if (prof) NSGP_HIP(hipEventRecord(pe[ei++], stream));
-        if (P->optimizer == NSGP_OPT_SGD)
-            hipLaunchKernelGGL(nsgp_lr_apply_kernel<NSGP_OPT_SGD>, dim3(g.lr2_n), dim3(256), 0, stream, t2 + g.lr2_off, P->d_layers, d);
-        else
-            hipLaunchKernelGGL(nsgp_lr_apply_kernel<NSGP_OPT_ADAM>, dim3(g.lr2_n), dim3(256), 0, stream, t2 + g.lr2_off, P->d_layers, d);
+#define LR_APPLY(OPTV, MAXRV) hipLaunchKernelGGL((nsgp_lr_apply_kernel<OPTV, MAXRV>), dim3(g.lr2_n), dim3(256), 0, stream, t2 + g.lr2_off, P->d_layers, d)
+        if (P->optimizer == NSGP_OPT_SGD) { if (g.wide) LR_APPLY(NSGP_OPT_SGD, 256); else LR_APPLY(NSGP_OPT_SGD, 128); }
+        else { if (g.wide) LR_APPLY(NSGP_OPT_ADAM, 256); else LR_APPLY(NSGP_OPT_ADAM, 128); }
+#undef LR_APPLY
         NSGP_LAUNCH_CHECK();
         if (prof) NSGP_HIP(hipEventRecord(pe[ei++], stream));
     }

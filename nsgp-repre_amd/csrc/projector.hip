@@ -88,7 +88,7 @@ __global__ __launch_bounds__(256) void nsgp_divide_kernel(float* __restrict__ P,
 }
 
 // Head form: P = I - U U^T from the r REMOVED directions, U [D][rpad] row-major fp32 (columns >= rank zero, rpad a
-// multiple of 32, <= 128), D % 32 == 0.  One wave per (32 rows x 256 columns) strip on v_mfma_f32_32x32x2_f32 with K = rpad;
+// multiple of 32 up to 128, or 256), D % 32 == 0.  One wave per (32 rows x 256 columns) strip on v_mfma_f32_32x32x2_f32 with K = rpad;
 // P[m][n] and P[n][m] are the same k-ordered chain of the same (commuting) products, so P is bit-symmetric.  This is the
 // form the low-rank step applies (projected_step.hip), so `u @ P` and `c (u - (u U) U^T)` agree to the rounding of P's entries.
 template <int NJ>
@@ -119,6 +119,33 @@ __device__ __forceinline__ void projector_head_body(const float* __restrict__ U,
     }
 }
 
+// rpad a multiple of 128 above 128: the same chain 128 k at a time (the fragments of a whole 256-wide row pair would not fit the registers)
+__device__ __forceinline__ void projector_head_wide(const float* __restrict__ U, float* __restrict__ P, int D, int rpad, int m0, int n0, int ncols) {
+    const int lane = threadIdx.x & 63;
+    const int i = lane & 31, h = lane >> 5;
+    const float* trow = U + (long)(m0 + i) * rpad + 4 * h;
+    for (int n = n0; n < n0 + ncols; n += 32) {
+        const float* urow = U + (long)(n + i) * rpad + 4 * h;
+        f32x16 acc;
+#pragma unroll
+        for (int v = 0; v < 16; ++v) acc[v] = 0.0f;
+        for (int k0 = 0; k0 < rpad; k0 += 128) {
+            f32x4 ta[16], ub[16];
+#pragma unroll
+            for (int q = 0; q < 16; ++q) { ta[q] = *(const gf32x4*)(trow + k0 + 8 * q); ub[q] = *(const gf32x4*)(urow + k0 + 8 * q); }
+#pragma unroll
+            for (int q = 0; q < 16; ++q)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ta[q][e], ub[q][e], acc, 0, 0, 0);
+        }
+#pragma unroll
+        for (int v = 0; v < 16; ++v) {
+            const int row = m0 + acc_row(v, lane), col = n + i;
+            as_global(P)[(long)row * D + col] = (row == col ? 1.0f : 0.0f) - acc[v];
+        }
+    }
+}
+
 __global__ __launch_bounds__(256) void nsgp_projector_head_kernel(const float* __restrict__ U, float* __restrict__ P, int D, int rpad) {
     const int strips = (D + 255) / 256;
     const int unit = blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -129,7 +156,8 @@ __global__ __launch_bounds__(256) void nsgp_projector_head_kernel(const float* _
         case 1: projector_head_body<1>(U, P, D, rpad, m0, n0, ncols); break;
         case 2: projector_head_body<2>(U, P, D, rpad, m0, n0, ncols); break;
         case 3: projector_head_body<3>(U, P, D, rpad, m0, n0, ncols); break;
-        default: projector_head_body<4>(U, P, D, rpad, m0, n0, ncols); break;
+        case 4: projector_head_body<4>(U, P, D, rpad, m0, n0, ncols); break;
+        default: projector_head_wide(U, P, D, rpad, m0, n0, ncols); break;      // rpad = 256 (129 .. 256 removed directions)
     }
 }
 
@@ -187,8 +215,8 @@ static int normalise_projector(float* P, int D, double* partial, hipStream_t str
 
 extern "C" int nsgp_build_projector_head(const float* U, int D, int rpad, int normalise, float* P, void* scratch,
                                          size_t scratch_bytes, void* stream_) {
-    if (!U || !P || D <= 0 || D % 32 != 0 || rpad <= 0 || rpad % 32 != 0 || rpad > 128 || !aligned16(U))
-        return fail(NSGP_ERR_INVALID, "nsgp_build_projector_head: bad argument (D=%d rpad=%d; D %% 32 == 0, rpad in {32,64,96,128}, U 16-byte aligned)", D, rpad);
+    if (!U || !P || D <= 0 || D % 32 != 0 || rpad <= 0 || rpad % 32 != 0 || (rpad > 128 && rpad != 256) || !aligned16(U))
+        return fail(NSGP_ERR_INVALID, "nsgp_build_projector_head: bad argument (D=%d rpad=%d; D %% 32 == 0, rpad in {32,64,96,128,256}, U 16-byte aligned)", D, rpad);
     if (!scratch || scratch_bytes < nsgp_projector_scratch_bytes(D)) return fail(NSGP_ERR_WORKSPACE, "nsgp_build_projector_head: scratch too small");
     hipStream_t stream = static_cast<hipStream_t>(stream_);
     const int units = (D / 32) * ((D + 255) / 256);

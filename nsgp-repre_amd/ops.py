@@ -99,7 +99,7 @@ def build_projector(V: torch.Tensor, first_col: int, normalise: bool, out: torch
 
 def build_projector_head(U: torch.Tensor, normalise: bool, out: torch.Tensor = None, return_norm: bool = False):
     """``P = I - U U^T`` (``/ ||P||_F`` if normalise) from the REMOVED directions ``U`` [D x rpad] (orthonormal columns,
-    zero-padded to a multiple of 32, at most 128) -- the projector of SGD_NSCL.py:270-285 written from the other side; the
+    zero-padded to a multiple of 32 up to 128, or to 256) -- the projector of SGD_NSCL.py:270-285 written from the other side; the
     form the low-rank step applies (``nsgp_build_projector_head``)."""
     lib = _lib.load_library()
     D, rpad = U.shape

@@ -29,7 +29,7 @@ from .threshold import elbow_index
 logger = logging.getLogger("nsgp_repre_amd")
 
 #: largest number of removed directions the low-rank form of the step takes (csrc/projected_step.hip: LR_MAX_RANK)
-LOW_RANK_MAX = 128
+LOW_RANK_MAX = 256
 
 #: default of ``optimizer.split_mfma`` (see NSCLOptimizerBase.__init__): False | "f16x2" (True = "f16x2")
 SPLIT_MFMA_DEFAULT = "f16x2"
@@ -281,7 +281,7 @@ class NSCLOptimizerBase(Optimizer):
             U = V[:, :rank]
             if self.polish_basis:       # on the r head columns only: an r x r Gram matrix, once per layer per task
                 U = 1.5 * U - 0.5 * (U @ (U.t() @ U))
-            rpad = 32 if rank <= 32 else (64 if rank <= 64 else 128)     # U's padded width (csrc: lr_rpad)
+            rpad = 32 if rank <= 32 else (64 if rank <= 64 else (128 if rank <= 128 else 256))     # U's padded width (csrc: lr_rpad)
             U_rm = torch.zeros(D, rpad, dtype=torch.float32, device=V.device)
             U_rm[:, :rank] = U
             U_kq = U_rm.view(D // 4, 4, rpad).permute(0, 2, 1).contiguous()     # k-quads [D/4][rpad][4]

@@ -814,7 +814,8 @@ def test_low_rank_form_at_full_layer_size(N, dev):
     assert _rel(lowr, dense) <= REL and _row_rel(lowr, dense) <= REL, (_rel(lowr, dense), _row_rel(lowr, dense))
 
 
-@pytest.mark.parametrize("D,first,norm", [(128, 20, True), (256, 33, False), (2304, 35, True), (512, 64, True), (1024, 100, False), (4608, 128, True), (160, 1, True)])
+@pytest.mark.parametrize("D,first,norm", [(128, 20, True), (256, 33, False), (2304, 35, True), (512, 64, True), (1024, 100, False), (4608, 128, True), (160, 1, True),
+                                          (1024, 129, True), (2304, 256, False), (4608, 200, True)])
 def test_build_projector_head_vs_oracle(N, dev, D, first, norm):
     """``nsgp_build_projector_head``: I - U U^T from the removed directions against the oracle's V_tail V_tail^T of the same
     (orthonormal) basis; bit-symmetric; and the complement of U to fp32 rounding (P U = 0)."""
@@ -826,7 +827,7 @@ def test_build_projector_head_vs_oracle(N, dev, D, first, norm):
     ref = (Q[:, first:] @ Q[:, first:].t())
     if norm:
         ref = ref / ref.norm()
-    rpad = 32 if first <= 32 else (64 if first <= 64 else 128)
+    rpad = 32 if first <= 32 else (64 if first <= 64 else (128 if first <= 128 else 256))
     U = torch.zeros(D, rpad)
     U[:, :first] = V[:, :first]
     P, nrm = ops.build_projector_head(U.to(dev), norm, return_norm=True)
@@ -1029,12 +1030,14 @@ def test_full_table_low_rank_default_vs_oracle_per_row(N, dev, depth):
 
 def test_low_rank_takes_misaligned_gradient_views_and_every_rank_class(N, dev):
     """Gradients that are views into a flat bucket at 4-byte-aligned offsets (DDP's gradient_as_bucket_view) on the low-rank
-    launches, for layers of each rank class (U padded to 32, 64 or 128 columns), SGD (Nesterov) / AdamW / AdamW-AMSGrad, against the oracle; a layer with
-    129 removed directions and one whose row count is not a 32-multiple take the dense GEMM with their head-form projector."""
+    launches, for layers of each rank class (U padded to 32, 64, 128 columns, and the WIDE class of 129 .. 256 removed directions with its own
+    pair of launches: one K range and five), SGD (Nesterov) / AdamW / AdamW-AMSGrad, against the oracle; a layer with 257 removed directions
+    and one whose row count is not a 32-multiple take the dense GEMM with their head-form projector."""
     ranks = {"backbone.r20.weight": 20, "neck.r33.weight": 33, "backbone.r96.weight": 96, "neck.r128.weight": 128, "backbone.r129.weight": 129,
-             "neck.rows48.weight": 10}
+             "neck.r200.weight": 200, "backbone.r256.weight": 256, "backbone.r257.weight": 257, "neck.rows48.weight": 10}
     shapes = {"backbone.r20.weight": (64, 160), "neck.r33.weight": (96, 32, 3, 3), "backbone.r96.weight": (32, 512, 1, 1),
-              "neck.r128.weight": (160, 384), "backbone.r129.weight": (128, 256), "neck.rows48.weight": (48, 64), "x.bias": (7,)}
+              "neck.r128.weight": (160, 384), "backbone.r129.weight": (128, 256), "neck.r200.weight": (96, 128, 3, 3),
+              "backbone.r256.weight": (64, 2304), "backbone.r257.weight": (64, 512), "neck.rows48.weight": (48, 64), "x.bias": (7,)}
     for kind in ("sgd", "adamw", "adamw_amsgrad"):
         gen = torch.Generator().manual_seed(31)
         init = {n: torch.randn(s, generator=gen) * 0.05 for n, s in shapes.items()}
@@ -1066,7 +1069,7 @@ def test_low_rank_takes_misaligned_gradient_views_and_every_rank_class(N, dev):
                 O.adamw_nscl_step(list(shapes), [cpu[n] for n in shapes], [grads[n].clone() for n in shapes], states, tr_cpu,
                                   lr=1e-3, weight_decay=0.05, amsgrad=kind.endswith("amsgrad"))
         torch.cuda.synchronize()
-        assert opt.lowrank_stats()[0] == 4, opt.lowrank_stats()          # r = 129 and the 48-row layer (head-form P, not a 32-multiple) take the dense GEMM
+        assert opt.lowrank_stats()[0] == 7, opt.lowrank_stats()          # r = 257 and the 48-row layer (head-form P, not a 32-multiple) take the dense GEMM
         _check(params, cpu, init, kind)
 
 
