@@ -58,7 +58,7 @@ int nsgp_debug_install_abort_backtrace(void);
  * tensor (momentum / Adam moments / weight decay, `p += update` for the
  * un-projected ones), and for the projected tensors either
  *   - the low-rank form `p += c (u - (u U) U^T)` for layers described with `basis` / `basis_rows`
- *     (head-form projectors, at most 128 removed directions): their elementwise update fused with
+ *     (head-form projectors, at most 256 removed directions: rank classes 32 / 64 / 128 share one pair of launches, 129 .. 256 have their own): their elementwise update fused with
  *     T = u U, a small ordered slab reduce, and the apply launch -- HBM-bound, exact fp32 MFMA; or
  *   - one grouped MFMA GEMM `p += update.view(Cout,D) @ P` (the `torch.mm(update.view(Cout,-1), P)`
  *     of SGD_NSCL.py:85-90) for every other projected tensor.

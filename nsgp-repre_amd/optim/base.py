@@ -9,7 +9,7 @@ the public ``eigens`` / ``transforms`` dicts and the extra param-group key
 What differs is *how* a step runs: instead of a Python loop of ~160 x 5 tiny
 elementwise launches plus 50 `torch.mm`, ``step()`` hands one table to
 ``nsgp_plan_step`` (C ABI) on the current stream: one multi-tensor HIP kernel, then -- for projectors this
-optimizer built itself (``get_transforms`` / ``set_basis``) with at most 128 removed directions -- the low-rank
+optimizer built itself (``get_transforms`` / ``set_basis``) with at most 256 removed directions -- the low-rank
 form ``p += c (u - (u U) U^T)`` (the layers' update fused with ``T = u U``, an ordered slab reduce, the apply launch:
 exact fp32 MFMA, HBM-bound), and for every other projector one
 grouped dense MFMA GEMM ``u @ P`` (two-term fp16 split by default, fp32 MFMA with ``split_mfma = False``).
