@@ -278,9 +278,12 @@ def repre_step(N, dev, K, split, reps=30):
     C_ = split[2] + 1
     fin, hid = 12544, 1024
 
+    head_params = list(head.parameters())
+
     def one(fused, amp, backward=True):
         rp.fused_replay = fused
-        head.zero_grad(set_to_none=True)
+        for p_ in head_params:          # what zero_grad(set_to_none=True) does, without walking the module tree inside the timed region
+            p_.grad = None
         if amp:
             with torch.autocast("cuda", dtype=torch.bfloat16):
                 loss = rp.replay_loss(rp.bbox_featss)["replay_loss"]["replay_loss_cls"]

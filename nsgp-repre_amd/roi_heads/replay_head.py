@@ -102,7 +102,8 @@ class PrototypeReplay:
         split, tid = list(h.task_split), h.task_id
         if split != list(self.task_split) or tid != self.task_id or len(h.fc_cls) != len(split):
             return None
-        live = list(h.fc_cls[:tid]) + [h.fc_cls[-1]]        # tasks 1..task_id + background: exactly the kept columns (head:495-497)
+        mods = list(h.fc_cls._modules.values())            # (slicing a ModuleList builds a new container: 20 us of a 0.2 ms host-bound pass)
+        live = mods[:tid] + [mods[-1]]                      # tasks 1..task_id + background: exactly the kept columns (head:495-497)
         if sum(m.out_features for m in live[:-1]) != split[tid] - split[0] or split[0] != 0:
             return None
         fc1, fc2 = h.shared_fcs
