@@ -79,8 +79,8 @@ def mean(v):
 traffic = {"source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE passes (kernels matching nsgp|repre only) of `python3 bench.py --steps 10 --warmup 2 "
                      "--hot-path-only` (tools/profile.sh); FETCH_SIZE x2 per the gfx950 correction"}
 for k in agg:
-    for tag, key in (("nsgp_project_v2_kernel<0>", "nsgp_project_kernel"), ("nsgp_update_lr_kernel<0>", "nsgp_update_lr_kernel"),
-                     ("nsgp_lr_apply_kernel<0>", "nsgp_lr_apply_kernel"), ("nsgp_update_kernel<0>", "nsgp_update_kernel")):
+    for tag, key in (("nsgp_project_v2_kernel<0>", "nsgp_project_kernel"), ("nsgp_update_lr_kernel<0, 1>", "nsgp_update_lr_kernel"),
+                     ("nsgp_lr_apply_kernel<0, 128>", "nsgp_lr_apply_kernel"), ("nsgp_update_kernel<0>", "nsgp_update_kernel")):      # <SGD, common rank classes>
         if tag not in k:
             continue
         if "FETCH_SIZE" in agg[k] and "WRITE_SIZE" in agg[k]:
