@@ -396,6 +396,21 @@ def test_grouped_covariance_pass_vs_single_layer_path_and_oracle(N, dev):
     assert sorted(res[True]) == sorted(res[False]) == ["0.weight", "2.weight", "4.weight"]
     for k in res[True]:
         assert _rel(res[True][k], res[False][k]) <= REL, k
+    # the same through the hooks with the correlation form forced for the 3x3 / 1 / 1 layer (the rule leaves a 24 x 32 map alone)
+    prev = ops.cov_set_corr_mode(2)
+    try:
+        col = N.runner.CovarianceCollector(net, [], grouped=True).register()
+        with torch.no_grad():
+            net(xin)
+            col.flush()
+            assert any(p.n_correlation_form == 1 for p in col._plans.values())
+            net(xin * 2)
+        col.remove()
+        col.close()
+    finally:
+        ops.cov_set_corr_mode(prev)
+    for k in res[False]:
+        assert _rel(col.fea_in[k], res[False][k]) <= REL, k
     # inputs of changing size (real loaders pad to many shapes): one plan per geometry, at most MAX_PLANS alive, ONE shared workspace
     col = N.runner.CovarianceCollector(net, [], grouped=True).register()
     col.MAX_PLANS = 2
