@@ -701,8 +701,8 @@ namespace nsgp {
 //                                LDS.  Every element of C is written by exactly one tile in a fixed k order: bitwise reproducible.
 // Layers the tile cannot take (D % 64 != 0: the 7x7 stem; Linear) stay on the single-layer entry points.
 //
-// CORRELATION FORM of the 3x3 / stride 1 / padding 1 convolutions (where almost all of the work is: the two 3x3s that see the
-// stride-4 FPN level are 70 % of an R-50-FPN forward's tile-steps).  Their covariance is 81 blocks of C x C,
+// CORRELATION FORM of the 3x3 / stride 1 / padding 1 convolutions (where almost all of the work is: the seventeen such layers are
+// 90 % of an R-50-FPN forward's im2col tile-steps, the one on the stride-4 FPN level alone 35 %).  Their covariance is 81 blocks of C x C,
 //     Cov[(c1,ky1,kx1), (c2,ky2,kx2)] = sum over output positions (y,x) of X[c1][y+ky1-1][x+kx1-1] X[c2][y+ky2-1][x+kx2-1],
 // and a block depends on its two kernel taps almost only through their DIFFERENCE (dy, dx) = (ky2-ky1, kx2-kx1): summed over the
 // EXTENDED position set y in [-1, H], x in [-1, W] (one ring more than the convolution has), every tap sweeps the whole image and
