@@ -212,7 +212,7 @@ int nsgp_cov_accumulate_conv2d(const float* x, int batch, int cin, int h, int w,
  * nsgp_cov_accumulate_conv2d (0: D = cin*kh*kw not a multiple of 64, or fewer than 32 output positions).  nsgp_cov_plan_run borrows
  * x[i] ([batch x cin x h x w] fp32), cov[i] ([D x D] fp32) for the layers of route 1 (entries of route-0 layers are ignored) and
  * assigns (accumulate[i] == 0) or adds; the covariances of one run must be distinct buffers.  workspace: >=
- * nsgp_cov_plan_workspace_bytes(plan), 16-byte aligned (the materialised two-term fp16 operands of all layers: ~2.4 GB for R-50-FPN at
+ * nsgp_cov_plan_workspace_bytes(plan), 16-byte aligned (the materialised two-term fp16 operands of all layers, slabs and correlation tables: ~2.5 GB for R-50-FPN at
  * 800 x 1344).  Deterministic: every element of C is produced by one tile in a fixed order. */
 typedef struct nsgp_cov_plan nsgp_cov_plan_t;
 typedef struct {
