@@ -39,7 +39,7 @@ def main():
     model.train()
     batches = [synthetic_batch(1, (15, 20), dev, seed=i) for i in range(4)]
     names = ["teacher.features", "teacher.rpn_predict", "teacher.roi_predict", "pseudo_label_filter", "student.features",
-             "student.rpn_loss_and_predict", "student.roi_loss", "student.replay_loss", "backward", "optimizer.step+zero_grad"]
+             "student.rpn_loss_and_predict", "student.roi_loss", "student.replay_loss", "backward", "optimizer.step", "optimizer.zero_grad"]
 
     def step(i, sync, acc):
         x, samples = batches[i % 4]
@@ -78,7 +78,8 @@ def main():
             roi_losses = head.add_replay_loss(roi_losses); mark()
         loss = sum(v for k, v in {**rpn_losses, **roi_losses}.items() if "loss" in k)
         loss.backward(); mark()
-        opt.step(); opt.zero_grad(); mark()
+        opt.step(); mark()
+        opt.zero_grad(); mark()
         if not sync:
             torch.cuda.synchronize()
             t.append(time.perf_counter())
