@@ -482,6 +482,13 @@ def _cpu_nsgp_fields(step_ms, timed, seconds_budget):
 PEAK_16BIT_MATRIX_TFLOPS = 2500.0   # dense fp16 / bf16 MFMA peak (MI355X_MICROARCH.md)
 
 
+SUSTAINED_HBM_GBS_3R2W = 5840.0     # measured, profiles/r03/hbm_peak_study.log (the higher of the two sizes)
+
+
+def gbs_of(ms, nbytes):
+    return nbytes / (ms * 1e-3) / 1e9 if ms else 0.0
+
+
 def _pmc_file():
     for name in ("r03/traffic.json", "r02/traffic.json", "r01_traffic.json"):
         f = os.path.join(ROOT, "profiles", name)
@@ -527,6 +534,10 @@ def roofline_block(split, flops, abytes_kernel, gemm_ms, update_ms, n_prof, nume
                                          "of the 50 projected layers (26.6 M elements)" + (" + g r+w, buf r+w, p r+w = 24 B per element of the un-projected "
                                                                                           "tensors (14.6 M elements)" if merged else ""))
         out.update({"profiled_steps": n_prof, "layers": nproj, "traffic": tr.get("nsgp_update_lr_kernel_hbm_bytes_per_launch"),
+                    "frac_of_sustained_hbm": gbs_of(fused_ms, fused_bytes) / SUSTAINED_HBM_GBS_3R2W,
+                    "sustained_hbm_note": f"a plain linear stream of this launch's access mix (3 reads + 2 writes, 16-byte non-temporal accesses) sustains "
+                                          f"{SUSTAINED_HBM_GBS_3R2W / 1e3:.2f} TB/s on an MI355X box (5.51-5.84 across sizes; read-only 7.1-7.25, copy 6.0: "
+                                          "tools/hbm_peak_bench.hip, profiles/r03/hbm_peak_study.log); `frac` stays priced against the 8 TB/s data-sheet figure",
                     "traffic_source": tr.get("source"),
                     "mfma_flops": lowrank[1] / 2, "mfma_frac_of_fp32_matrix_peak": lowrank[1] / 2 / (fused_ms * 1e-3) / 1e12 / PEAK_FP32_MATRIX_TFLOPS,
                     "nsgp_step_launches": ("" if merged else "nsgp_update_kernel -> ") + "nsgp_update_lr_kernel -> nsgp_lr_reduce_kernel -> nsgp_lr_apply_kernel",
