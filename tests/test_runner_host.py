@@ -287,6 +287,10 @@ def test_task_flow_pieces_of_the_mixin(N):
         assert nxt.load_previous_checkpoint(net2).endswith("best_x.pth")
         assert torch.equal(net2.conv.weight, net.conv.weight)
         assert nxt.rr_thresh == [0.5, 0.5]                                   # runner:356 default
+        assert (nxt.cov_grouped, nxt.cov_streams) == (True, 4)               # how cal_fea_in issues the covariance launches: the defaults ...
+        alt = N.runner.br_nullspace_runner.NullSpaceTaskMixin()
+        alt.init_task_state(w2, task_id=2, previous_dir=w1, cov_grouped=False, cov_streams=1)
+        assert (alt.cov_grouped, alt.cov_streams) == (False, 1)              # ... and the reference's own order of operations (per hook, one stream)
         loaded = nxt.load_importance(net2)
         assert sorted(nxt.reg_params) == ["bn1.bias", "bn1.weight"] and len(loaded["importance"]["bn1.weight"]) == 1
 
