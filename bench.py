@@ -639,10 +639,15 @@ def end_to_end_training(N, dev, world, local_rank, basis_cache, steps, warmup, a
         # find_unused_parameters=True is the reference's own setting (_base_/brnsrunetime.py:27); the frozen heads of future tasks
         # and the teacher never receive gradients
         net = torch.nn.parallel.DistributedDataParallel(model, device_ids=[local_rank], broadcast_buffers=False,
-                                                        gradient_as_bucket_view=True, find_unused_parameters=True)
+                                                        gradient_as_bucket_view=os.environ.get("NSGP_BENCH_BUCKET_VIEW", "1") == "1",
+                                                        find_unused_parameters=os.environ.get("NSGP_BENCH_FIND_UNUSED", "1") == "1")      # (rehearsal knobs; the driver sets neither)
     fwd_bwd, opt_ms = [], []
 
+    verbose = bool(os.environ.get("NSGP_BENCH_DUMP_AFTER"))
+
     def one_step(i):
+        if verbose:
+            print(f"[rank {os.environ.get('RANK', 0)}] step {i} begins", file=sys.stderr, flush=True)
         x, samples = batches[i % len(batches)]
         e0, e1, e2 = (torch.cuda.Event(enable_timing=True) for _ in range(3))
         e0.record()
@@ -883,6 +888,9 @@ def main():
                     "step on every MFMA path + replay loss on synthetic gradients -- no detector, no once-per-task units")
     args = ap.parse_args()
 
+    if os.environ.get("NSGP_BENCH_DUMP_AFTER"):      # rehearsal aid: every thread's Python stack to stderr after that many seconds, then exit
+        import faulthandler
+        faulthandler.dump_traceback_later(float(os.environ["NSGP_BENCH_DUMP_AFTER"]), exit=True)
     rank = int(os.environ.get("RANK", 0))
     local_rank = int(os.environ.get("LOCAL_RANK", 0))
     world = int(os.environ.get("WORLD_SIZE", 1))
